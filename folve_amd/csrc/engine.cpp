@@ -1,0 +1,690 @@
+// engine.cpp — host side of the gfx950 convolution engine behind include/folve_engine.h.
+//
+// Owns device memory and launch order; all arithmetic is in kernels/kernels.hip.
+// There is deliberately no CPU compute path here: every failure to reach the
+// GPU surfaces as FE_ERR_DEVICE.
+#include "../../include/folve_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels/kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(FE_ERR_DEVICE, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kJobSlots = 8;
+
+}  // namespace
+
+struct fe_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+    std::map<int, float2*> tw;              // log2P -> exp(-2 pi i k / 2P), k < 2P
+    float2* Y = nullptr;
+    size_t Y_rows_bytes = 0;
+    // rotating pinned/device buffers for job descriptors (async uploads)
+    fk::StreamJob* jobs_host[kJobSlots] = {};
+    fk::StreamJob* jobs_dev[kJobSlots] = {};
+    size_t jobs_cap[kJobSlots] = {};
+    hipEvent_t jobs_ev[kJobSlots] = {};
+    bool jobs_ev_pending[kJobSlots] = {};
+    int jobs_next = 0;
+    // staging for host-pointer calls
+    float* stage_in = nullptr;
+    size_t stage_in_bytes = 0;
+    float* stage_out = nullptr;
+    size_t stage_out_bytes = 0;
+    // profiling
+    bool profiling = false;
+    hipEvent_t pev[4] = {};
+    long long prof_launches[FE_K_COUNT] = {};
+    double prof_ms[FE_K_COUNT] = {};
+};
+
+struct PathHost {
+    bool used = false;
+    int link = -1;                 // index of the path whose data this one shares
+    std::vector<float> taps;       // K*P when populated
+    uint32_t mask[4] = {0, 0, 0, 0};
+};
+
+struct fe_filter {
+    fe_engine* eng = nullptr;
+    std::atomic<int> refs{1};
+    int ninp = 0, nout = 0, size = 0, P = 0, log2P = 0, K = 0;
+    float density = 0.f;
+    bool committed = false;
+    std::vector<PathHost> paths;   // [inp * nout + out]
+    // device side (after commit)
+    int ndata = 0;
+    float2* H = nullptr;
+    uint32_t* mask_dev = nullptr;
+    fk::PathEntry* paths_dev = nullptr;
+    int* out_first_dev = nullptr;
+    fk::FilterDev dev{};
+};
+
+struct fe_stream {
+    fe_filter* f = nullptr;
+    fe_engine* eng = nullptr;
+    int max_blocks = 1, ring = 1;
+    float2* fdl = nullptr;
+    size_t fdl_bytes = 0;
+    float* tails = nullptr;        // [2][cin][P]
+    unsigned int* peaks = nullptr; // [2]
+    long long blocks_done = 0;
+    int slot0 = 0;
+    int parity = 0;
+};
+
+namespace {
+
+int resolve(const fe_filter* f, int idx) {
+    int guard = 0;
+    while (f->paths[idx].link >= 0 && guard++ < 8192) idx = f->paths[idx].link;
+    return idx;
+}
+
+int get_twiddles(fe_engine* e, int log2P, const float2** out) {
+    auto it = e->tw.find(log2P);
+    if (it != e->tw.end()) { *out = it->second; return FE_OK; }
+    const int n = 2 << log2P;  // 2P entries
+    std::vector<float2> host((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)n;
+        host[(size_t)k] = float2{(float)std::cos(a), (float)std::sin(a)};
+    }
+    float2* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, sizeof(float2) * (size_t)n));
+    HIP_TRY(hipMemcpy(dev, host.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    e->tw[log2P] = dev;
+    *out = dev;
+    return FE_OK;
+}
+
+int ensure_bytes(fe_engine* e, void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return FE_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));   // nothing in flight may still use the old buffer
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *have = 0;
+    size_t cap = need + need / 4;
+    HIP_TRY(hipMalloc(ptr, cap));
+    *have = cap;
+    return FE_OK;
+}
+
+struct Item {
+    fe_stream* s;
+    const float* in;     // device
+    float* out;          // device
+    long long left;
+};
+
+// One launch round over streams that share a filter.
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any) {
+    const int P = f->P;
+    std::vector<fk::StreamJob> jobs;
+    jobs.reserve(items.size());
+    int yunits = 0, max_blocks = 0;
+    for (Item& it : items) {
+        if (it.left <= 0) continue;
+        fe_stream* s = it.s;
+        const long long cap = (long long)s->max_blocks * P;
+        const long long take = std::min(it.left, cap);
+        fk::StreamJob j{};
+        j.in = it.in;
+        j.out = it.out;
+        j.fdl = s->fdl;
+        const size_t tail_elems = (size_t)f->ninp * P;
+        j.tail_rd = s->tails + (size_t)s->parity * tail_elems;
+        j.tail_wr = s->tails + (size_t)(s->parity ^ 1) * tail_elems;
+        j.peaks = s->peaks;
+        j.nframes = take;
+        j.nblocks = (int)((take + P - 1) / P);
+        j.slot0 = s->slot0;
+        j.yunit0 = yunits;
+        j.ring = s->ring;
+        yunits += j.nblocks * f->nout;
+        max_blocks = std::max(max_blocks, j.nblocks);
+        jobs.push_back(j);
+        // advance host-side state now: everything below is stream-ordered
+        s->slot0 = (s->slot0 + j.nblocks) % s->ring;
+        s->parity ^= 1;
+        s->blocks_done += j.nblocks;
+        it.in += (size_t)take * f->ninp;
+        it.out += (size_t)take * f->nout;
+        it.left -= take;
+    }
+    *any = !jobs.empty();
+    if (jobs.empty()) return FE_OK;
+
+    int rc = ensure_bytes(e, (void**)&e->Y, &e->Y_rows_bytes, (size_t)yunits * P * sizeof(float2));
+    if (rc) return rc;
+
+    // upload the descriptors through a rotating pinned buffer
+    const int slot = e->jobs_next;
+    e->jobs_next = (e->jobs_next + 1) % kJobSlots;
+    if (e->jobs_ev_pending[slot]) {
+        HIP_TRY(hipEventSynchronize(e->jobs_ev[slot]));
+        e->jobs_ev_pending[slot] = false;
+    }
+    const size_t bytes = jobs.size() * sizeof(fk::StreamJob);
+    if (e->jobs_cap[slot] < bytes) {
+        if (e->jobs_host[slot]) HIP_TRY(hipHostFree(e->jobs_host[slot]));
+        if (e->jobs_dev[slot]) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->jobs_dev[slot])); }
+        e->jobs_host[slot] = nullptr; e->jobs_dev[slot] = nullptr; e->jobs_cap[slot] = 0;
+        const size_t cap = std::max<size_t>(bytes * 2, 64 * sizeof(fk::StreamJob));
+        HIP_TRY(hipHostMalloc((void**)&e->jobs_host[slot], cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&e->jobs_dev[slot], cap));
+        e->jobs_cap[slot] = cap;
+    }
+    memcpy(e->jobs_host[slot], jobs.data(), bytes);
+    HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipEventRecord(e->jobs_ev[slot], e->stream));
+    e->jobs_ev_pending[slot] = true;
+
+    const fk::StreamJob* dj = e->jobs_dev[slot];
+    const int nj = (int)jobs.size();
+    const bool prof = e->profiling;
+    if (prof) HIP_TRY(hipEventRecord(e->pev[0], e->stream));
+    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, e->stream));
+    if (prof) HIP_TRY(hipEventRecord(e->pev[1], e->stream));
+    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, e->Y, max_blocks, e->stream));
+    if (prof) HIP_TRY(hipEventRecord(e->pev[2], e->stream));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, e->Y, e->stream));
+    if (prof) {
+        HIP_TRY(hipEventRecord(e->pev[3], e->stream));
+        HIP_TRY(hipEventSynchronize(e->pev[3]));
+        for (int k = 0; k < FE_K_COUNT; ++k) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->pev[k], e->pev[k + 1]));
+            e->prof_ms[k] += ms;
+            e->prof_launches[k] += 1;
+        }
+    }
+    return FE_OK;
+}
+
+int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
+                   const long long* nframes, float* const* out, int flags) {
+    const bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
+    const bool async = device_ptrs && (flags & FE_ASYNC);
+    HIP_TRY(hipSetDevice(e->device));
+
+    std::vector<Item> all((size_t)n);
+    size_t in_floats = 0, out_floats = 0;
+    for (int i = 0; i < n; ++i) {
+        fe_stream* s = streams[i];
+        if (!s || s->eng != e) return fail(FE_ERR_PARAM, "stream %d is null or on another engine", i);
+        if (nframes[i] < 0) return fail(FE_ERR_PARAM, "negative frame count");
+        if (nframes[i] > 0 && (!in[i] || !out[i])) return fail(FE_ERR_PARAM, "null buffer for stream %d", i);
+        for (int k = 0; k < i; ++k)
+            if (streams[k] == s) return fail(FE_ERR_PARAM, "stream listed twice in one batch");
+        all[(size_t)i] = Item{s, in[i], out[i], nframes[i]};
+        in_floats += (size_t)nframes[i] * s->f->ninp;
+        out_floats += (size_t)nframes[i] * s->f->nout;
+    }
+    if (!device_ptrs) {
+        int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_bytes(e, (void**)&e->stage_out, &e->stage_out_bytes, out_floats * sizeof(float));
+        if (rc) return rc;
+        size_t io = 0, oo = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t ni = (size_t)nframes[i] * streams[i]->f->ninp, no = (size_t)nframes[i] * streams[i]->f->nout;
+            if (ni) HIP_TRY(hipMemcpyAsync(e->stage_in + io, in[i], ni * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            all[(size_t)i].in = e->stage_in + io;
+            all[(size_t)i].out = e->stage_out + oo;
+            io += ni;
+            oo += no;
+        }
+    }
+    // group by filter; each group runs launch rounds until its frames are consumed
+    std::vector<char> done((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[(size_t)i]) continue;
+        fe_filter* f = streams[i]->f;
+        std::vector<Item> group;
+        std::vector<int> idx;
+        for (int k = i; k < n; ++k)
+            if (!done[(size_t)k] && streams[k]->f == f) { group.push_back(all[(size_t)k]); idx.push_back(k); done[(size_t)k] = 1; }
+        bool any = true;
+        while (any) {
+            int rc = launch_round(e, f, group, &any);
+            if (rc) return rc;
+        }
+    }
+    if (!device_ptrs) {
+        size_t oo = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t no = (size_t)nframes[i] * streams[i]->f->nout;
+            if (no) HIP_TRY(hipMemcpyAsync(out[i], e->stage_out + oo, no * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            oo += no;
+        }
+    }
+    if (!async) HIP_TRY(hipStreamSynchronize(e->stream));
+    return FE_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char* fe_last_error(void) { return g_last_error.c_str(); }
+
+int fe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fe_fragm_for_size(unsigned int maxsize) {
+    unsigned int fragm = FE_MAXQUANT;
+    while (fragm > FE_MINPART && fragm >= 2 * maxsize) fragm /= 2;
+    return (int)fragm;
+}
+
+int fe_engine_create(int device, void* hip_stream, fe_engine** out) {
+    if (!out) return fail(FE_ERR_PARAM, "null out");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FE_ERR_DEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(FE_ERR_PARAM, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    fe_engine* e = new (std::nothrow) fe_engine();
+    if (!e) return fail(FE_ERR_ALLOC, "out of memory");
+    e->device = device;
+    if (hip_stream) {
+        e->stream = (hipStream_t)hip_stream;
+    } else {
+        hipError_t r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (r != hipSuccess) { delete e; return fail(FE_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(r)); }
+        e->own_stream = true;
+    }
+    for (int i = 0; i < kJobSlots; ++i) {
+        if (hipEventCreateWithFlags(&e->jobs_ev[i], hipEventDisableTiming) != hipSuccess) {
+            delete e;
+            return fail(FE_ERR_DEVICE, "hipEventCreate failed");
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (hipEventCreate(&e->pev[i]) != hipSuccess) { delete e; return fail(FE_ERR_DEVICE, "hipEventCreate failed"); }
+    }
+    *out = e;
+    return FE_OK;
+}
+
+void fe_engine_destroy(fe_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->tw) (void)hipFree(kv.second);
+    if (e->Y) (void)hipFree(e->Y);
+    if (e->stage_in) (void)hipFree(e->stage_in);
+    if (e->stage_out) (void)hipFree(e->stage_out);
+    for (int i = 0; i < kJobSlots; ++i) {
+        if (e->jobs_host[i]) (void)hipHostFree(e->jobs_host[i]);
+        if (e->jobs_dev[i]) (void)hipFree(e->jobs_dev[i]);
+        if (e->jobs_ev[i]) (void)hipEventDestroy(e->jobs_ev[i]);
+    }
+    for (int i = 0; i < 4; ++i) if (e->pev[i]) (void)hipEventDestroy(e->pev[i]);
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int fe_engine_synchronize(fe_engine* e) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FE_OK;
+}
+
+int fe_engine_device(const fe_engine* e) { return e ? e->device : -1; }
+
+// ---- filter ---------------------------------------------------------------
+int fe_filter_create(fe_engine* e, int ninp, int nout, int maxsize, float density, fe_filter** out) {
+    if (!out) return fail(FE_ERR_PARAM, "null out");
+    *out = nullptr;
+    // e may be NULL: such a filter can be assembled and inspected but not committed
+    if (ninp < 1 || ninp > FE_MAXINP) return fail(FE_ERR_PARAM, "inputs %d out of range", ninp);
+    if (nout < 1 || nout > FE_MAXOUT) return fail(FE_ERR_PARAM, "outputs %d out of range", nout);
+    if (maxsize < 1 || maxsize > FE_MAXSIZE) return fail(FE_ERR_PARAM, "size %d out of range", maxsize);
+    if (!(density >= 0.0f && density <= 1.0f)) return fail(FE_ERR_PARAM, "density out of range");
+    fe_filter* f = new (std::nothrow) fe_filter();
+    if (!f) return fail(FE_ERR_ALLOC, "out of memory");
+    f->eng = e;
+    f->ninp = ninp; f->nout = nout; f->size = maxsize; f->density = density;
+    f->P = fe_fragm_for_size((unsigned)maxsize);
+    f->log2P = 0;
+    while ((1 << f->log2P) < f->P) f->log2P++;
+    f->K = (maxsize + f->P - 1) / f->P;
+    f->paths.resize((size_t)ninp * nout);
+    *out = f;
+    return FE_OK;
+}
+
+int fe_filter_add(fe_filter* f, int inp, int out, int step, const float* data, int ind0, int ind1) {
+    if (!f) return fail(FE_ERR_PARAM, "null filter");
+    if (f->committed) return fail(FE_ERR_STATE, "filter already committed");
+    if (inp < 0 || inp >= f->ninp || out < 0 || out >= f->nout) return fail(FE_ERR_PARAM, "bad input/output");
+    if (ind0 < 0 || ind1 < ind0 || step < 1 || (!data && ind1 > ind0)) return fail(FE_ERR_PARAM, "bad range");
+    const int self = inp * f->nout + out;
+    f->paths[(size_t)self].used = true;
+    PathHost& p = f->paths[(size_t)resolve(f, self)];
+    p.used = true;
+    const long long cap = (long long)f->K * f->P;
+    if (p.taps.empty()) {
+        try { p.taps.assign((size_t)cap, 0.0f); } catch (...) { return fail(FE_ERR_ALLOC, "out of memory"); }
+    }
+    const long long hi = std::min<long long>(ind1, cap);
+    for (long long t = ind0; t < hi; ++t) p.taps[(size_t)t] += data[(size_t)(t - ind0) * (size_t)step];
+    if (hi > ind0) {
+        for (int k = ind0 / f->P; k <= (int)((hi - 1) / f->P); ++k) p.mask[k >> 5] |= 1u << (k & 31);
+    }
+    return FE_OK;
+}
+
+int fe_filter_link(fe_filter* f, int inp1, int out1, int inp2, int out2) {
+    if (!f) return fail(FE_ERR_PARAM, "null filter");
+    if (f->committed) return fail(FE_ERR_STATE, "filter already committed");
+    if (inp1 < 0 || inp1 >= f->ninp || out1 < 0 || out1 >= f->nout) return fail(FE_ERR_PARAM, "bad source pair");
+    if (inp2 < 0 || inp2 >= f->ninp || out2 < 0 || out2 >= f->nout) return fail(FE_ERR_PARAM, "bad target pair");
+    const int src = inp1 * f->nout + out1, dst = inp2 * f->nout + out2;
+    if (src == dst) return fail(FE_ERR_PARAM, "cannot link a pair to itself");
+    if (resolve(f, src) == dst) return fail(FE_ERR_PARAM, "link would form a cycle");
+    PathHost& d = f->paths[(size_t)dst];
+    d.taps.clear();
+    d.taps.shrink_to_fit();
+    memset(d.mask, 0, sizeof(d.mask));
+    d.link = src;
+    d.used = true;
+    return FE_OK;
+}
+
+int fe_filter_commit(fe_filter* f) {
+    if (!f) return fail(FE_ERR_PARAM, "null filter");
+    if (f->committed) return FE_OK;
+    fe_engine* e = f->eng;
+    if (!e) return fail(FE_ERR_DEVICE, "filter has no engine: cannot commit (no CPU fallback)");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const int P = f->P, K = f->K, np = f->ninp * f->nout;
+    std::vector<int> data_of((size_t)np, -1);
+    std::vector<int> owners;
+    for (int i = 0; i < np; ++i) {
+        const PathHost& p = f->paths[(size_t)i];
+        if (p.used && p.link < 0 && !p.taps.empty()) { data_of[(size_t)i] = (int)owners.size(); owners.push_back(i); }
+    }
+    f->ndata = (int)owners.size();
+    std::vector<fk::PathEntry> entries;
+    std::vector<int> out_first((size_t)f->nout + 1, 0);
+    for (int o = 0; o < f->nout; ++o) {
+        out_first[(size_t)o] = (int)entries.size();
+        for (int i = 0; i < f->ninp; ++i) {
+            const int idx = i * f->nout + o;
+            if (!f->paths[(size_t)idx].used) continue;
+            const int d = data_of[(size_t)resolve(f, idx)];
+            if (d >= 0) entries.push_back(fk::PathEntry{i, d});
+        }
+    }
+    out_first[(size_t)f->nout] = (int)entries.size();
+
+    const float2* tw = nullptr;
+    int rc = get_twiddles(e, f->log2P, &tw);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc((void**)&f->out_first_dev, out_first.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(f->out_first_dev, out_first.data(), out_first.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!entries.empty()) {
+        HIP_TRY(hipMalloc((void**)&f->paths_dev, entries.size() * sizeof(fk::PathEntry)));
+        HIP_TRY(hipMemcpy(f->paths_dev, entries.data(), entries.size() * sizeof(fk::PathEntry), hipMemcpyHostToDevice));
+    }
+    if (f->ndata > 0) {
+        const size_t per = (size_t)K * P;
+        std::vector<uint32_t> masks((size_t)f->ndata * 4);
+        float* taps_dev = nullptr;
+        HIP_TRY(hipMalloc((void**)&taps_dev, per * f->ndata * sizeof(float)));
+        for (int d = 0; d < f->ndata; ++d) {
+            const PathHost& p = f->paths[(size_t)owners[(size_t)d]];
+            memcpy(&masks[(size_t)d * 4], p.mask, sizeof(p.mask));
+            hipError_t r = hipMemcpy(taps_dev + per * d, p.taps.data(), per * sizeof(float), hipMemcpyHostToDevice);
+            if (r != hipSuccess) { (void)hipFree(taps_dev); return fail(FE_ERR_DEVICE, "tap upload: %s", hipGetErrorString(r)); }
+        }
+        HIP_TRY(hipMalloc((void**)&f->H, per * f->ndata * sizeof(float2)));
+        HIP_TRY(hipMalloc((void**)&f->mask_dev, masks.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(f->mask_dev, masks.data(), masks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(fk::launch_filter_transform(taps_dev, f->H, f->ndata, K, f->log2P, tw, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(taps_dev));
+    }
+    f->dev.cin = f->ninp; f->dev.cout = f->nout; f->dev.P = P; f->dev.log2P = f->log2P; f->dev.K = K;
+    f->dev.H = f->H; f->dev.mask = f->mask_dev; f->dev.paths = f->paths_dev; f->dev.out_first = f->out_first_dev;
+    f->dev.tw = tw;
+    f->committed = true;
+    return FE_OK;
+}
+
+void fe_filter_retain(fe_filter* f) { if (f) f->refs.fetch_add(1); }
+
+void fe_filter_release(fe_filter* f) {
+    if (!f) return;
+    if (f->refs.fetch_sub(1) != 1) return;
+    if (f->eng) {
+        (void)hipSetDevice(f->eng->device);
+        if (f->committed) (void)hipStreamSynchronize(f->eng->stream);
+    }
+    if (f->H) (void)hipFree(f->H);
+    if (f->mask_dev) (void)hipFree(f->mask_dev);
+    if (f->paths_dev) (void)hipFree(f->paths_dev);
+    if (f->out_first_dev) (void)hipFree(f->out_first_dev);
+    delete f;
+}
+
+int fe_filter_inputs(const fe_filter* f) { return f ? f->ninp : 0; }
+int fe_filter_outputs(const fe_filter* f) { return f ? f->nout : 0; }
+int fe_filter_block_size(const fe_filter* f) { return f ? f->P : 0; }
+int fe_filter_partitions(const fe_filter* f) { return f ? f->K : 0; }
+int fe_filter_maxsize(const fe_filter* f) { return f ? f->size : 0; }
+
+int fe_filter_path_partitions(const fe_filter* f, int inp, int out) {
+    if (!f || inp < 0 || inp >= f->ninp || out < 0 || out >= f->nout) return 0;
+    const int idx = inp * f->nout + out;
+    if (!f->paths[(size_t)idx].used) return 0;
+    const PathHost& p = f->paths[(size_t)resolve(f, idx)];
+    int n = 0;
+    for (int w = 0; w < 4; ++w) n += __builtin_popcount(p.mask[w]);
+    return n;
+}
+
+int fe_filter_get_taps(const fe_filter* f, int inp, int out, float* dst, int n) {
+    if (!f || !dst || n < 0) return fail(FE_ERR_PARAM, "bad argument");
+    if (inp < 0 || inp >= f->ninp || out < 0 || out >= f->nout) return fail(FE_ERR_PARAM, "bad input/output");
+    memset(dst, 0, sizeof(float) * (size_t)n);
+    const int idx = inp * f->nout + out;
+    if (!f->paths[(size_t)idx].used) return FE_OK;
+    const PathHost& p = f->paths[(size_t)resolve(f, idx)];
+    const size_t m = std::min<size_t>((size_t)n, p.taps.size());
+    if (m) memcpy(dst, p.taps.data(), m * sizeof(float));
+    return FE_OK;
+}
+
+// ---- stream ---------------------------------------------------------------
+int fe_stream_open(fe_filter* f, int max_blocks_per_call, fe_stream** out) {
+    if (!out) return fail(FE_ERR_PARAM, "null out");
+    *out = nullptr;
+    if (!f) return fail(FE_ERR_PARAM, "null filter");
+    if (!f->committed) return fail(FE_ERR_STATE, "filter not committed");
+    if (max_blocks_per_call < 1 || max_blocks_per_call > 4096) return fail(FE_ERR_PARAM, "max_blocks_per_call out of range");
+    fe_engine* e = f->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    fe_stream* s = new (std::nothrow) fe_stream();
+    if (!s) return fail(FE_ERR_ALLOC, "out of memory");
+    s->f = f; s->eng = e;
+    s->max_blocks = max_blocks_per_call;
+    s->ring = f->K - 1 + max_blocks_per_call;
+    s->fdl_bytes = (size_t)f->ninp * s->ring * f->P * sizeof(float2);
+    const size_t tail_bytes = (size_t)2 * f->ninp * f->P * sizeof(float);
+    hipError_t r = hipMalloc((void**)&s->fdl, s->fdl_bytes);
+    if (r == hipSuccess) r = hipMalloc((void**)&s->tails, tail_bytes);
+    if (r == hipSuccess) r = hipMalloc((void**)&s->peaks, 2 * sizeof(unsigned int));
+    if (r == hipSuccess) r = hipMemsetAsync(s->fdl, 0, s->fdl_bytes, e->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(s->tails, 0, tail_bytes, e->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream);
+    if (r != hipSuccess) {
+        if (s->fdl) (void)hipFree(s->fdl);
+        if (s->tails) (void)hipFree(s->tails);
+        if (s->peaks) (void)hipFree(s->peaks);
+        delete s;
+        return fail(r == hipErrorOutOfMemory ? FE_ERR_ALLOC : FE_ERR_DEVICE, "stream allocation: %s", hipGetErrorString(r));
+    }
+    fe_filter_retain(f);
+    *out = s;
+    return FE_OK;
+}
+
+int fe_stream_reset(fe_stream* s) {
+    if (!s) return fail(FE_ERR_PARAM, "null stream");
+    fe_engine* e = s->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(s->fdl, 0, s->fdl_bytes, e->stream));
+    HIP_TRY(hipMemsetAsync(s->tails, 0, (size_t)2 * s->f->ninp * s->f->P * sizeof(float), e->stream));
+    HIP_TRY(hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream));
+    s->slot0 = 0;
+    s->parity = 0;
+    s->blocks_done = 0;
+    return FE_OK;
+}
+
+void fe_stream_close(fe_stream* s) {
+    if (!s) return;
+    fe_engine* e = s->eng;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        (void)hipSetDevice(e->device);
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(s->fdl);
+        (void)hipFree(s->tails);
+        (void)hipFree(s->peaks);
+    }
+    fe_filter_release(s->f);
+    delete s;
+}
+
+int fe_stream_get_peaks(fe_stream* s, float* peak_signed, float* peak_abs) {
+    if (!s) return fail(FE_ERR_PARAM, "null stream");
+    fe_engine* e = s->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned int bits[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(bits, s->peaks, sizeof(bits), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    float v[2];
+    memcpy(v, bits, sizeof(v));
+    if (peak_signed) *peak_signed = v[0];
+    if (peak_abs) *peak_abs = v[1];
+    return FE_OK;
+}
+
+int fe_stream_reset_peaks(fe_stream* s) {
+    if (!s) return fail(FE_ERR_PARAM, "null stream");
+    fe_engine* e = s->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream));
+    return FE_OK;
+}
+
+long long fe_stream_blocks_done(const fe_stream* s) { return s ? s->blocks_done : 0; }
+
+int fe_batch_process(fe_stream* const* streams, int n, const float* const* in, const long long* nframes,
+                     float* const* out, int flags) {
+    if (n < 0 || (n > 0 && (!streams || !in || !nframes || !out))) return fail(FE_ERR_PARAM, "bad batch arguments");
+    if (n == 0) return FE_OK;
+    if (!streams[0]) return fail(FE_ERR_PARAM, "null stream");
+    fe_engine* e = streams[0]->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return process_locked(e, streams, n, in, nframes, out, flags);
+}
+
+int fe_stream_process_blocks(fe_stream* s, const float* in, long long nframes, float* out) {
+    fe_stream* ss[1] = {s};
+    const float* ii[1] = {in};
+    float* oo[1] = {out};
+    long long nn[1] = {nframes};
+    return fe_batch_process(ss, 1, ii, nn, oo, FE_HOST_PTRS);
+}
+
+int fe_stream_process(fe_stream* s, const float* in, int valid_frames, float* out, float* peak_signed,
+                      float* peak_abs) {
+    if (!s) return fail(FE_ERR_PARAM, "null stream");
+    if (valid_frames < 1 || valid_frames > s->f->P) return fail(FE_ERR_PARAM, "valid_frames must be in 1..block size");
+    int rc = fe_stream_process_blocks(s, in, valid_frames, out);
+    if (rc) return rc;
+    if (peak_signed || peak_abs) rc = fe_stream_get_peaks(s, peak_signed, peak_abs);
+    return rc;
+}
+
+// ---- measurement hooks ------------------------------------------------------
+int fe_engine_set_profiling(fe_engine* e, int on) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->profiling = on != 0;
+    return FE_OK;
+}
+
+int fe_engine_get_profile(fe_engine* e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (int k = 0; k < FE_K_COUNT; ++k) {
+        if (launches) launches[k] = e->prof_launches[k];
+        if (ms) ms[k] = e->prof_ms[k];
+    }
+    return FE_OK;
+}
+
+int fe_engine_reset_profile(fe_engine* e) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (int k = 0; k < FE_K_COUNT; ++k) { e->prof_launches[k] = 0; e->prof_ms[k] = 0.0; }
+    return FE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+/* folve_engine.h — C ABI of the MI355X (gfx950) convolution engine for folve.
+ *
+ * This is the drop-in boundary underneath folve's SoundProcessor /
+ * ProcessorPool.  The reference has no C ABI at this seam: its
+ * `SoundProcessor` (sound-processor.h:28-85) drives the C++ `Convproc` object
+ * of libzita-convolver directly.  Every entry point below therefore cites the
+ * Convproc / SoundProcessor call it replaces.  Plain pointers and sizes only;
+ * nothing throws across this boundary; every function returns 0 or a negative
+ * FE_* code (folve only ever tests `!= 0`, zita-config.cc:163,203,252,274).
+ *
+ * Threading contract (the reference's): at most one thread is
+ * inside a given stream at a time; different streams may be driven from
+ * different threads; a committed filter is immutable and shareable.
+ *
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails with FE_ERR_DEVICE.
+ */
+#ifndef FOLVE_ENGINE_H
+#define FOLVE_ENGINE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FE_ABI_VERSION 1
+
+/* Limits of the engine being replaced, as used by zita-fconfig.cc:49,55,74-75
+ * (Convproc::MAXINP/MAXOUT/MAXQUANT/MINPART) and zita-config.h:61 (MAXSIZE). */
+#define FE_MAXINP 64
+#define FE_MAXOUT 64
+#define FE_MAXQUANT 8192
+#define FE_MINPART 64
+#define FE_MAXSIZE 0x00100000
+
+enum {
+    FE_OK = 0,
+    FE_ERR_STATE = -1,   /* call not valid in this state (e.g. add after commit) */
+    FE_ERR_PARAM = -2,   /* bad argument */
+    FE_ERR_ALLOC = -3,   /* host or device allocation failed */
+    FE_ERR_DEVICE = -4,  /* no usable HIP device / HIP runtime error */
+    FE_ERR_BUSY = -5
+};
+
+/* flags for fe_batch_process */
+enum {
+    FE_HOST_PTRS = 0,    /* in/out are host pointers; the call returns when out is filled */
+    FE_DEVICE_PTRS = 1,  /* in/out are device pointers on the engine's GPU */
+    FE_ASYNC = 2         /* with FE_DEVICE_PTRS: enqueue only, do not wait */
+};
+
+typedef struct fe_engine fe_engine;   /* one GPU: HIP stream, tables, scratch */
+typedef struct fe_filter fe_filter;   /* a configured convolver matrix (what config() builds) */
+typedef struct fe_stream fe_stream;   /* per-file convolver state (what a pooled SoundProcessor owns) */
+
+/* ---- engine ------------------------------------------------------------- */
+int fe_device_count(void);
+/* hip_stream: a hipStream_t to launch on, or NULL for a private stream. */
+int fe_engine_create(int device, void *hip_stream, fe_engine **out);
+void fe_engine_destroy(fe_engine *e);
+int fe_engine_synchronize(fe_engine *e);
+int fe_engine_device(const fe_engine *e);
+const char *fe_last_error(void);      /* thread-local detail of the last failure */
+
+/* ---- filter: replaces Convproc::configure / impdata_create / impdata_copy - */
+/* fragm = MAXQUANT; while (fragm > MINPART && fragm >= 2*size) fragm /= 2
+ * (zita-fconfig.cc:74-77). */
+int fe_fragm_for_size(unsigned int maxsize);
+/* Convproc::configure(ninp, nout, size, fragm, fragm, fragm, density)
+ * (zita-fconfig.cc:80-81); the block size is derived as above. */
+int fe_filter_create(fe_engine *e, int ninp, int nout, int maxsize, float density, fe_filter **out);
+/* Convproc::impdata_create(inp, out, step, data, ind0, ind1) (zita-config.cc:163,
+ * 203,252): ADDS data[k*step] at taps ind0+k; 0-based channels. */
+int fe_filter_add(fe_filter *f, int inp, int out, int step, const float *data, int ind0, int ind1);
+/* Convproc::impdata_copy(inp1, out1, inp2, out2) (zita-config.cc:274):
+ * (inp2,out2) shares the spectra of (inp1,out1), later additions included. */
+int fe_filter_link(fe_filter *f, int inp1, int out1, int inp2, int out2);
+/* Transform the partitions on the GPU and make the filter immutable.  Until
+ * then nothing touches the device (the loader is testable without a GPU). */
+int fe_filter_commit(fe_filter *f);
+/* Reference counting: create returns 1 reference; each open stream holds one. */
+void fe_filter_retain(fe_filter *f);
+void fe_filter_release(fe_filter *f);
+int fe_filter_inputs(const fe_filter *f);
+int fe_filter_outputs(const fe_filter *f);
+int fe_filter_block_size(const fe_filter *f);     /* P = fragm */
+int fe_filter_partitions(const fe_filter *f);     /* K = ceil(size / P) */
+int fe_filter_maxsize(const fe_filter *f);
+/* populated partitions of path inp->out (links followed), 0 if no path */
+int fe_filter_path_partitions(const fe_filter *f, int inp, int out);
+/* copy the assembled float32 taps of path inp->out (links followed) into dst[0..n) */
+int fe_filter_get_taps(const fe_filter *f, int inp, int out, float *dst, int n);
+
+/* ---- stream: replaces Convproc's per-instance state ----------------------- */
+/* max_blocks_per_call bounds how many consecutive blocks one call may carry
+ * (FDL ring = K-1+max_blocks rows per input channel); longer spans are split. */
+int fe_stream_open(fe_filter *f, int max_blocks_per_call, fe_stream **out);
+/* Convproc::reset() (sound-processor.cc:140): zero all state, zero latency. */
+int fe_stream_reset(fe_stream *s);
+void fe_stream_close(fe_stream *s);
+/* Exactly SoundProcessor::Process() (sound-processor.cc:98-127) for one block:
+ * `in` holds valid_frames (<= P) interleaved input frames, the rest of the
+ * block is zero; `out` receives valid_frames interleaved output frames.  Peaks
+ * are the running maxima since the last reset: signed (as cc:120-123 compares)
+ * and absolute.  Host pointers; synchronous. */
+int fe_stream_process(fe_stream *s, const float *in, int valid_frames, float *out,
+                      float *peak_signed, float *peak_abs);
+/* Run-ahead form: nframes interleaved frames = ceil(nframes/P) blocks, the last
+ * zero-padded; time advances by whole blocks.  Host pointers; synchronous. */
+int fe_stream_process_blocks(fe_stream *s, const float *in, long long nframes, float *out);
+int fe_stream_get_peaks(fe_stream *s, float *peak_signed, float *peak_abs);
+int fe_stream_reset_peaks(fe_stream *s);
+long long fe_stream_blocks_done(const fe_stream *s);
+
+/* ---- batch: many independent streams in one launch ------------------------ */
+/* streams[i] consumes nframes[i] interleaved frames from in[i] and produces as
+ * many into out[i].  All streams must live on one engine; streams of different
+ * filters are launched in groups.  flags: FE_HOST_PTRS or FE_DEVICE_PTRS[|FE_ASYNC]. */
+int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
+                     float *const *out, int flags);
+
+/* ---- measurement hooks (bench.py: per-kernel HIP-event timing) ------------ */
+enum { FE_K_FORWARD = 0, FE_K_MAC = 1, FE_K_INVERSE = 2, FE_K_COUNT = 3 };
+int fe_engine_set_profiling(fe_engine *e, int on);
+/* accumulated since the last reset: launches and milliseconds per kernel */
+int fe_engine_get_profile(fe_engine *e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]);
+int fe_engine_reset_profile(fe_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOLVE_ENGINE_H */

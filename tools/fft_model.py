@@ -1,0 +1,111 @@
+"""numpy model of the index math used by folve_amd/csrc/kernels (design aid).
+
+Validates, against numpy.fft, the exact formulas the HIP kernels implement:
+  * Stockham autosort passes with a mixed radix plan,
+  * real FFT of a 2P window through a P-point complex FFT, packed spectrum
+    (bin 0 holds (DC, Nyquist)),
+  * packed multiply-accumulate,
+  * inverse through the P-point complex FFT, overlap-save (keep last P).
+Run: python tools/fft_model.py
+"""
+import numpy as np
+
+
+def plan(log2n):
+    r, out = log2n, []
+    while r >= 4 and r != 5:
+        out.append(16); r -= 4
+    while r >= 3:
+        out.append(8); r -= 3
+    if r == 2: out.append(4)
+    if r == 1: out.append(2)
+    assert np.prod(out) == 1 << log2n
+    return out
+
+
+def stockham(z, inverse=False):
+    n = len(z)
+    sign = 1.0 if inverse else -1.0
+    a = z.astype(np.complex128).copy()
+    ns = 1
+    for R in plan(int(np.log2(n))):
+        b = np.empty_like(a)
+        j = np.arange(n // R)
+        k = j % ns
+        v = np.stack([a[j + r * (n // R)] * np.exp(sign * 2j * np.pi * k * r / (ns * R)) for r in range(R)])
+        # R-point DFT, natural order
+        W = np.exp(sign * 2j * np.pi * np.outer(np.arange(R), np.arange(R)) / R)
+        v = W @ v
+        j0 = (j - k) * R + k
+        for r in range(R):
+            b[j0 + r * ns] = v[r]
+        a = b
+        ns *= R
+    return a
+
+
+def fwd_packed(win):
+    """win: 2P real -> packed P complex (bin0 = DC + i*Nyq)."""
+    P = len(win) // 2
+    z = win[0::2] + 1j * win[1::2]
+    Z = stockham(z)
+    X = np.empty(P, np.complex128)
+    X[0] = (Z[0].real + Z[0].imag) + 1j * (Z[0].real - Z[0].imag)
+    k = np.arange(1, P)
+    Zk, Zc = Z[k], np.conj(Z[P - k])
+    E = 0.5 * (Zk + Zc)
+    O = -0.5j * (Zk - Zc)
+    X[k] = E + np.exp(-1j * np.pi * k / P) * O
+    return X
+
+
+def inv_packed(Y):
+    """packed P complex -> 2P real * (2P) (unnormalised)."""
+    P = len(Y)
+    Z = np.empty(P, np.complex128)
+    Z[0] = (Y[0].real + Y[0].imag) + 1j * (Y[0].real - Y[0].imag)
+    k = np.arange(1, P)
+    Yk, Yc = Y[k], np.conj(Y[P - k])
+    E = Yk + Yc
+    O = (Yk - Yc) * np.exp(1j * np.pi * k / P)
+    Z[k] = E + 1j * O
+    z = stockham(Z, inverse=True)
+    y = np.empty(2 * P)
+    y[0::2] = z.real
+    y[1::2] = z.imag
+    return y
+
+
+def mac_packed(acc, X, H):
+    acc[0] += X[0].real * H[0].real + 1j * (X[0].imag * H[0].imag)
+    acc[1:] += X[1:] * H[1:]
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    for P in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+        z = rng.standard_normal(P) + 1j * rng.standard_normal(P)
+        assert np.allclose(stockham(z), np.fft.fft(z))
+        assert np.allclose(stockham(z, True), np.fft.ifft(z) * P)
+        w = rng.standard_normal(2 * P)
+        X = fwd_packed(w)
+        F = np.fft.rfft(w)
+        assert np.allclose(X[1:], F[1:P]) and np.isclose(X[0].real, F[0].real) and np.isclose(X[0].imag, F[P].real)
+        assert np.allclose(inv_packed(X), w * 2 * P)
+        # overlap-save partitioned convolution through packed spectra
+        K, nb = 3, 6
+        h = rng.standard_normal(K * P)
+        x = rng.standard_normal(nb * P)
+        Hs = [fwd_packed(np.concatenate([h[j * P:(j + 1) * P], np.zeros(P)])) / (2 * P) for j in range(K)]
+        xp = np.concatenate([np.zeros(P), x])
+        Xs = [fwd_packed(xp[n * P:(n + 2) * P]) for n in range(nb)]
+        y = np.zeros(nb * P)
+        for n in range(nb):
+            acc = np.zeros(P, np.complex128)
+            for j in range(K):
+                if n - j >= 0:
+                    mac_packed(acc, Xs[n - j], Hs[j])
+            y[n * P:(n + 1) * P] = inv_packed(acc)[P:]
+        ref = np.convolve(x, h)[: nb * P]
+        assert np.allclose(y, ref), (P, np.abs(y - ref).max())
+        print("P=%d ok plan=%s" % (P, plan(int(np.log2(P)))))
