@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -79,6 +80,14 @@ def lib():
         raise ImportError(
             "folve_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C folve_amd/csrc`. There is no CPU fallback." % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7;
+    # importing it first lets the dynamic linker satisfy our DT_NEEDED entry with
+    # that copy, so torch tensors' device pointers are valid in the engine.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     for name, res, args in ENGINE_SYMBOLS:
         fn = getattr(L, name)

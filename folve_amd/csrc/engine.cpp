@@ -47,6 +47,7 @@ constexpr int kJobSlots = 8;
 }  // namespace
 
 struct fe_engine {
+    std::atomic<int> refs{1};     // creator + one per live filter (streams hold their filter)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -351,8 +352,9 @@ int fe_engine_create(int device, void* hip_stream, fe_engine** out) {
     return FE_OK;
 }
 
-void fe_engine_destroy(fe_engine* e) {
+static void engine_release(fe_engine* e) {
     if (!e) return;
+    if (e->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->tw) (void)hipFree(kv.second);
@@ -368,6 +370,10 @@ void fe_engine_destroy(fe_engine* e) {
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
+
+// Drops the creator's reference; the engine lives on until the last filter
+// (and so the last stream) created on it is gone.
+void fe_engine_destroy(fe_engine* e) { engine_release(e); }
 
 int fe_engine_synchronize(fe_engine* e) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");
@@ -390,6 +396,7 @@ int fe_filter_create(fe_engine* e, int ninp, int nout, int maxsize, float densit
     fe_filter* f = new (std::nothrow) fe_filter();
     if (!f) return fail(FE_ERR_ALLOC, "out of memory");
     f->eng = e;
+    if (e) e->refs.fetch_add(1);
     f->ninp = ninp; f->nout = nout; f->size = maxsize; f->density = density;
     f->P = fe_fragm_for_size((unsigned)maxsize);
     f->log2P = 0;
@@ -513,7 +520,9 @@ void fe_filter_release(fe_filter* f) {
     if (f->mask_dev) (void)hipFree(f->mask_dev);
     if (f->paths_dev) (void)hipFree(f->paths_dev);
     if (f->out_first_dev) (void)hipFree(f->out_first_dev);
+    fe_engine* e = f->eng;
     delete f;
+    engine_release(e);
 }
 
 int fe_filter_inputs(const fe_filter* f) { return f ? f->ninp : 0; }
