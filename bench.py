@@ -178,7 +178,7 @@ def main():
         nthreads = cores
         nstreams = nthreads
         tprobe = O.bench_streams(nstreams, 1, nthreads, C, C, size, 3)
-        nblocks = int(max(2, min(64, args.cpu_seconds / max(tprobe, 1e-3))))
+        nblocks = int(max(2, min(1024, args.cpu_seconds / max(tprobe, 1e-3))))
         tcpu = O.bench_streams(nstreams, nblocks, nthreads, C, C, size, 3)
         cpu = {"value": round(nstreams * nblocks * P * C / tcpu / 1e6, 2), "unit": "Msamples/s", "cores": nthreads,
                "kind": "port",
