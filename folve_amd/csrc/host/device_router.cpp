@@ -1,0 +1,120 @@
+#include "device_router.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace folve {
+
+DeviceRouter* DeviceRouter::Default() {
+    static DeviceRouter* router = [] {
+        std::vector<int> devs;
+        if (const char* env = getenv("FOLVE_AMD_DEVICES")) {
+            const char* p = env;
+            while (*p) {
+                char* end = NULL;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                devs.push_back(static_cast<int>(d));
+                p = (*end == ',') ? end + 1 : end;
+            }
+        } else {
+            const int n = fe_device_count();
+            for (int d = 0; d < n; ++d) devs.push_back(d);
+        }
+        return new DeviceRouter(devs);
+    }();
+    return router;
+}
+
+DeviceRouter::DeviceRouter(const std::vector<int>& devices) {
+    for (int d : devices) slots_.push_back(Slot{d, NULL, 0});
+}
+
+DeviceRouter::~DeviceRouter() {
+    for (auto& kv : filters_) fe_filter_release(kv.second.filter);
+    for (Slot& s : slots_)
+        if (s.engine) fe_engine_destroy(s.engine);
+}
+
+fe_engine* DeviceRouter::PickEngine() {
+    std::lock_guard<std::mutex> lk(mu_);
+    Slot* best = NULL;
+    for (Slot& s : slots_)
+        if (!best || s.live < best->live) best = &s;
+    if (!best) return NULL;
+    if (!best->engine && fe_engine_create(best->device, NULL, &best->engine) != 0) {
+        Logf("GPU %d unusable: %s", best->device, fe_last_error());
+        return NULL;
+    }
+    return best->engine;
+}
+
+fe_engine* DeviceRouter::EngineForDevice(int device) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (Slot& s : slots_) {
+        if (s.device != device) continue;
+        if (!s.engine && fe_engine_create(s.device, NULL, &s.engine) != 0) {
+            Logf("GPU %d unusable: %s", s.device, fe_last_error());
+            return NULL;
+        }
+        return s.engine;
+    }
+    return NULL;
+}
+
+void DeviceRouter::StreamOpened(fe_engine* e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (Slot& s : slots_) if (s.engine == e) s.live++;
+}
+
+void DeviceRouter::StreamClosed(fe_engine* e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (Slot& s : slots_) if (s.engine == e && s.live > 0) s.live--;
+}
+
+int DeviceRouter::live_streams(int slot) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)].live : 0;
+}
+
+fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_file, time_t mtime, int samplerate,
+                                   int channels, ZitaConfig* out_cfg) {
+    // Serialised like the reference serialises Create() (sound-processor.cc:43).
+    std::lock_guard<std::mutex> lk(mu_);
+    const std::pair<std::string, int> key(config_file, fe_engine_device(engine));
+    auto it = filters_.find(key);
+    if (it != filters_.end()) {
+        if (it->second.mtime == mtime) {
+            *out_cfg = it->second.cfg;
+            out_cfg->config_file = NULL;
+            fe_filter_retain(it->second.filter);
+            return it->second.filter;
+        }
+        fe_filter_release(it->second.filter);    // configuration file was touched: rebuild
+        filters_.erase(it);
+    }
+    ZitaConfig zita;
+    memset(&zita, 0, sizeof(zita));
+    zita.engine = engine;
+    zita.fsamp = samplerate;
+    zita.ninp = channels;
+    zita.nout = channels;
+    // As SoundProcessor::Create (sound-processor.cc:44-46): parse errors, or a
+    // configuration that never defined a convolver, make creation fail.
+    if (config(&zita, config_file.c_str()) != 0 || zita.filter == NULL) {
+        if (zita.filter) fe_filter_release(zita.filter);
+        return NULL;
+    }
+    if (fe_filter_commit(zita.filter) != 0) {
+        Logf("Cannot transform filter %s on GPU %d: %s", config_file.c_str(), key.second, fe_last_error());
+        fe_filter_release(zita.filter);
+        return NULL;
+    }
+    zita.config_file = NULL;
+    filters_[key] = CachedFilter{zita.filter, zita, mtime};
+    *out_cfg = zita;
+    fe_filter_retain(zita.filter);
+    return zita.filter;
+}
+
+}  // namespace folve

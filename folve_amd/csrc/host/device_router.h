@@ -1,0 +1,50 @@
+// device_router.h — the ProcessorPool's GPU sharder.
+//
+// folve hands one SoundProcessor to one open file; streams are independent, so
+// the multi-GPU form of the pool is "pick a GPU per new processor, keep it there"
+// (SURVEY.md §8e).  One engine per visible device, created lazily; a new stream
+// goes to the device with the fewest live streams.  Committed filters are cached
+// per (config path, mtime, device) so that all streams of one configuration on a
+// GPU share a single set of spectra — which is also what lets them be batched.
+#pragma once
+
+#include <time.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "zita_config.h"
+
+namespace folve {
+
+class DeviceRouter {
+public:
+    // Process-wide router over all visible devices (or FOLVE_AMD_DEVICES="0,2,3").
+    static DeviceRouter* Default();
+    explicit DeviceRouter(const std::vector<int>& devices);
+    ~DeviceRouter();
+
+    int device_count() const { return static_cast<int>(slots_.size()); }
+    // Engine of the least-loaded device (created on first use); NULL without a GPU.
+    fe_engine* PickEngine();
+    fe_engine* EngineForDevice(int device);
+    void StreamOpened(fe_engine* e);
+    void StreamClosed(fe_engine* e);
+    int live_streams(int slot) const;
+
+    // Parsed + committed filter for (config, mtime) on `engine`; NULL if the
+    // configuration is broken.  The caller gets its own reference.
+    fe_filter* GetFilter(fe_engine* engine, const std::string& config_file, time_t mtime, int samplerate,
+                         int channels, ZitaConfig* out_cfg);
+
+private:
+    struct Slot { int device; fe_engine* engine; int live; };
+    struct CachedFilter { fe_filter* filter; ZitaConfig cfg; time_t mtime; };
+    mutable std::mutex mu_;
+    std::vector<Slot> slots_;
+    std::map<std::pair<std::string, int>, CachedFilter> filters_;   // (config path, device) -> filter
+};
+
+}  // namespace folve

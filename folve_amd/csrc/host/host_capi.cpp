@@ -1,0 +1,125 @@
+// host_capi.cpp — extern "C" view of the host classes (include/folve_host.h).
+#include "../../../include/folve_host.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+
+#include "device_router.h"
+#include "processor_pool.h"
+#include "sound_processor.h"
+#include "sstring.h"
+#include "zita_config.h"
+
+using folve::ProcessorPool;
+using folve::SoundProcessor;
+
+namespace {
+
+// FrameSource / FrameSink over caller-provided float spans.
+class SpanSource : public folve::FrameSource {
+public:
+    SpanSource(const float* src, int frames, int channels) : src_(src), left_(frames), ch_(channels) {}
+    int ReadFrames(float* dst, int frames) override {
+        const int n = std::min(frames, left_);
+        memcpy(dst, src_, sizeof(float) * static_cast<size_t>(n) * ch_);
+        src_ += static_cast<size_t>(n) * ch_;
+        left_ -= n;
+        return n;
+    }
+private:
+    const float* src_;
+    int left_, ch_;
+};
+
+class SpanSink : public folve::FrameSink {
+public:
+    SpanSink(float* dst, int channels) : dst_(dst), ch_(channels) {}
+    int WriteFrames(const float* src, int frames) override {
+        memcpy(dst_, src, sizeof(float) * static_cast<size_t>(frames) * ch_);
+        dst_ += static_cast<size_t>(frames) * ch_;
+        return frames;
+    }
+private:
+    float* dst_;
+    int ch_;
+};
+
+inline SoundProcessor* SP(fh_processor* p) { return reinterpret_cast<SoundProcessor*>(p); }
+inline const SoundProcessor* SP(const fh_processor* p) { return reinterpret_cast<const SoundProcessor*>(p); }
+inline ProcessorPool* PP(fh_pool* p) { return reinterpret_cast<ProcessorPool*>(p); }
+
+}  // namespace
+
+extern "C" {
+
+int fh_sstring(const char* srce, char* dest, int size) { return folve::sstring(srce, dest, size); }
+
+int fh_config_load(fe_engine* engine, const char* config_file, int fsamp, int channels, fe_filter** filter,
+                   int* fragm, int* ninp, int* nout, int* size) {
+    folve::ZitaConfig z;
+    memset(&z, 0, sizeof(z));
+    z.engine = engine;
+    z.fsamp = fsamp;
+    z.ninp = channels;
+    z.nout = channels;
+    const int stat = folve::config(&z, config_file);
+    if (filter) *filter = z.filter; else if (z.filter) fe_filter_release(z.filter);
+    if (fragm) *fragm = z.fragm;
+    if (ninp) *ninp = z.ninp;
+    if (nout) *nout = z.nout;
+    if (size) *size = z.size;
+    return stat;
+}
+
+fh_processor* fh_processor_create(const char* config_file, int samplerate, int channels) {
+    return reinterpret_cast<fh_processor*>(SoundProcessor::Create(config_file, samplerate, channels));
+}
+void fh_processor_destroy(fh_processor* p) { delete SP(p); }
+
+int fh_processor_fill_buffer(fh_processor* p, const float* src, int frames_available) {
+    SpanSource s(src, frames_available, SP(p)->input_channels());
+    return SP(p)->FillBuffer(&s);
+}
+void fh_processor_write_processed(fh_processor* p, float* dst, int sample_count) {
+    SpanSink s(dst, SP(p)->output_channels());
+    SP(p)->WriteProcessed(&s, sample_count);
+}
+int fh_processor_is_input_buffer_complete(const fh_processor* p) { return SP(p)->is_input_buffer_complete(); }
+int fh_processor_pending_writes(const fh_processor* p) { return SP(p)->pending_writes(); }
+int fh_processor_input_channels(const fh_processor* p) { return SP(p)->input_channels(); }
+int fh_processor_output_channels(const fh_processor* p) { return SP(p)->output_channels(); }
+int fh_processor_block_size(const fh_processor* p) { return SP(p)->block_size(); }
+float fh_processor_max_output_value(const fh_processor* p) { return SP(p)->max_output_value(); }
+float fh_processor_max_abs_output_value(const fh_processor* p) { return SP(p)->max_abs_output_value(); }
+void fh_processor_reset_max_values(fh_processor* p) { SP(p)->ResetMaxValues(); }
+void fh_processor_reset(fh_processor* p) { SP(p)->Reset(); }
+const char* fh_processor_config_file(const fh_processor* p) { return SP(p)->config_file().c_str(); }
+long long fh_processor_config_file_timestamp(const fh_processor* p) { return SP(p)->config_file_timestamp(); }
+int fh_processor_config_still_up_to_date(const fh_processor* p) { return SP(p)->ConfigStillUpToDate(); }
+int fh_processor_device(const fh_processor* p) { return SP(p)->device(); }
+fe_stream* fh_processor_stream(const fh_processor* p) { return SP(p)->stream(); }
+
+fh_pool* fh_pool_create(int max_per_config) { return reinterpret_cast<fh_pool*>(new ProcessorPool(max_per_config)); }
+void fh_pool_destroy(fh_pool* pool) { delete PP(pool); }
+
+fh_processor* fh_pool_get_or_create(fh_pool* pool, const char* base_dir, int sampling_rate, int channels, int bits,
+                                    char* errmsg, int errmsg_size) {
+    std::string err;
+    SoundProcessor* p = PP(pool)->GetOrCreate(base_dir, sampling_rate, channels, bits, &err);
+    if (errmsg && errmsg_size > 0) {
+        strncpy(errmsg, err.c_str(), static_cast<size_t>(errmsg_size) - 1);
+        errmsg[errmsg_size - 1] = 0;
+    }
+    return reinterpret_cast<fh_processor*>(p);
+}
+void fh_pool_return(fh_pool* pool, fh_processor* p) { PP(pool)->Return(SP(p)); }
+int fh_pool_pooled_count(fh_pool* pool, const char* config_path) {
+    return static_cast<int>(PP(pool)->pooled_count(config_path));
+}
+
+int fh_router_device_count(void) { return folve::DeviceRouter::Default()->device_count(); }
+int fh_router_live_streams(int slot) { return folve::DeviceRouter::Default()->live_streams(slot); }
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+#include "processor_pool.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <vector>
+
+#include "sound_processor.h"
+
+namespace folve {
+
+namespace {
+
+std::string Fmt(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+std::string Fmt(const char* fmt, ...) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return buf;
+}
+
+bool FirstReadable(const std::vector<std::string>& candidates, std::string* match) {
+    for (const std::string& c : candidates) {
+        if (access(c.c_str(), R_OK) == 0) {
+            *match = c;
+            return true;
+        }
+    }
+    return false;
+}
+
+}  // namespace
+
+ProcessorPool::ProcessorPool(int max_available) : max_per_config_(static_cast<size_t>(max_available)) {}
+
+ProcessorPool::~ProcessorPool() {
+    for (auto& kv : pool_) {
+        for (SoundProcessor* p : *kv.second) delete p;
+        delete kv.second;
+    }
+}
+
+SoundProcessor* ProcessorPool::GetOrCreate(const std::string& base_dir, int sampling_rate, int channels, int bits,
+                                           std::string* errmsg) {
+    // From specific to non-specific (processor-pool.cc:53-61).
+    std::vector<std::string> path_choices;
+    path_choices.push_back(Fmt("%s/filter-%d-%d-%d.conf", base_dir.c_str(), sampling_rate, channels, bits));
+    path_choices.push_back(Fmt("%s/filter-%d-%d.conf", base_dir.c_str(), sampling_rate, channels));
+    path_choices.push_back(Fmt("%s/filter-%d.conf", base_dir.c_str(), sampling_rate));
+
+    std::string config_path;
+    if (!FirstReadable(path_choices, &config_path)) {
+        const char* slash = strrchr(base_dir.c_str(), '/');
+        const char* short_dir = slash ? slash + 1 : base_dir.c_str();
+        *errmsg = Fmt("No filter in %s for %.1fkHz/%d ch/%d bits", short_dir, sampling_rate / 1000.0, channels, bits);
+        return NULL;
+    }
+    SoundProcessor* result;
+    while ((result = CheckOutOfPool(config_path)) != NULL) {
+        if (result->ConfigStillUpToDate()) break;
+        Logf("Processor %p: outdated; config file changed %s", static_cast<void*>(result), config_path.c_str());
+        delete result;
+    }
+    if (result != NULL) return result;
+
+    result = SoundProcessor::Create(config_path, sampling_rate, channels);
+    if (result == NULL) {
+        *errmsg = "Problem parsing " + config_path;
+        Logf("filter-config %s is broken.", config_path.c_str());
+    }
+    return result;
+}
+
+void ProcessorPool::Return(SoundProcessor* processor) {
+    if (processor == NULL) return;
+    if (!processor->ConfigStillUpToDate()) {
+        delete processor;     // outdated: not returning it to the pool
+        return;
+    }
+    std::lock_guard<std::mutex> l(pool_mutex_);
+    ProcessorList*& list = pool_[processor->config_file()];
+    if (list == NULL) list = new ProcessorList();
+    if (list->size() < max_per_config_) {
+        processor->Reset();
+        list->push_back(processor);
+    } else {
+        delete processor;     // enough processors in pool
+    }
+}
+
+SoundProcessor* ProcessorPool::CheckOutOfPool(const std::string& config_path) {
+    std::lock_guard<std::mutex> l(pool_mutex_);
+    PoolMap::iterator found = pool_.find(config_path);
+    if (found == pool_.end()) return NULL;
+    ProcessorList* list = found->second;
+    if (list->empty()) return NULL;
+    SoundProcessor* result = list->front();
+    list->pop_front();
+    return result;
+}
+
+size_t ProcessorPool::pooled_count(const std::string& config_path) {
+    std::lock_guard<std::mutex> l(pool_mutex_);
+    PoolMap::iterator found = pool_.find(config_path);
+    return (found == pool_.end()) ? 0 : found->second->size();
+}
+
+}  // namespace folve

@@ -1,5 +1,43 @@
-"""ctypes declarations for include/folve_host.h (SoundProcessor / ProcessorPool mirror)."""
-HOST_SYMBOLS = []
+"""ctypes binding of include/folve_host.h: the SoundProcessor / ProcessorPool / config-loader mirror."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+_pi = C.POINTER(C.c_int)
+HOST_SYMBOLS = [
+    ("fh_sstring", _i, [C.c_char_p, C.c_char_p, _i]),
+    ("fh_config_load", _i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp), _pi, _pi, _pi, _pi]),
+    ("fh_processor_create", _vp, [C.c_char_p, _i, _i]),
+    ("fh_processor_destroy", None, [_vp]),
+    ("fh_processor_fill_buffer", _i, [_vp, _vp, _i]),
+    ("fh_processor_write_processed", None, [_vp, _vp, _i]),
+    ("fh_processor_is_input_buffer_complete", _i, [_vp]),
+    ("fh_processor_pending_writes", _i, [_vp]),
+    ("fh_processor_input_channels", _i, [_vp]),
+    ("fh_processor_output_channels", _i, [_vp]),
+    ("fh_processor_block_size", _i, [_vp]),
+    ("fh_processor_max_output_value", _f, [_vp]),
+    ("fh_processor_max_abs_output_value", _f, [_vp]),
+    ("fh_processor_reset_max_values", None, [_vp]),
+    ("fh_processor_reset", None, [_vp]),
+    ("fh_processor_config_file", C.c_char_p, [_vp]),
+    ("fh_processor_config_file_timestamp", _ll, [_vp]),
+    ("fh_processor_config_still_up_to_date", _i, [_vp]),
+    ("fh_processor_device", _i, [_vp]),
+    ("fh_processor_stream", _vp, [_vp]),
+    ("fh_pool_create", _vp, [_i]),
+    ("fh_pool_destroy", None, [_vp]),
+    ("fh_pool_get_or_create", _vp, [_vp, C.c_char_p, _i, _i, _i, C.c_char_p, _i]),
+    ("fh_pool_return", None, [_vp, _vp]),
+    ("fh_pool_pooled_count", _i, [_vp, C.c_char_p]),
+    ("fh_router_device_count", _i, []),
+    ("fh_router_live_streams", _i, [_i]),
+]
+
+# zita-config.h:51
+NOERR, ERR_OTHER, ERR_SYNTAX, ERR_PARAM, ERR_ALLOC, ERR_CANTCD, ERR_COMMAND, ERR_NOCONV, ERR_IONUM = range(9)
 
 
 def declare(L):
@@ -7,3 +45,141 @@ def declare(L):
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+
+
+def _L():
+    from .capi import lib
+    return lib()
+
+
+def sstring(src: bytes, size=1024):
+    buf = C.create_string_buffer(max(size, 1) + 8)
+    n = _L().fh_sstring(src, buf, size)
+    return n, buf.value
+
+
+def config_load(config_file, fsamp=44100, channels=2, engine=None):
+    """Parse a jconvolver config into an uncommitted Filter (host only when engine is None).
+    Returns (status, Filter or None, dict(fragm, ninp, nout, size))."""
+    from .capi import Filter
+    fh = C.c_void_p()
+    vals = [C.c_int() for _ in range(4)]
+    st = _L().fh_config_load(engine.h if engine is not None else None, os.fsencode(config_file), fsamp, channels,
+                             C.byref(fh), *[C.byref(v) for v in vals])
+    flt = None
+    if fh.value:
+        flt = Filter.from_handle(fh, engine)
+        _L().fe_filter_release(fh)      # from_handle took its own reference
+    return st, flt, dict(zip(("fragm", "ninp", "nout", "size"), [v.value for v in vals]))
+
+
+class SoundProcessor:
+    """folve::SoundProcessor driven over float spans (what ConvolveFileHandler does with SNDFILE*)."""
+
+    def __init__(self, handle, owned=True):
+        self.h = handle
+        self.owned = owned
+        L = _L()
+        self.ninp = L.fh_processor_input_channels(handle)
+        self.nout = L.fh_processor_output_channels(handle)
+        self.fragm = L.fh_processor_block_size(handle)
+
+    @classmethod
+    def create(cls, config_file, samplerate, channels):
+        h = _L().fh_processor_create(os.fsencode(config_file), samplerate, channels)
+        return cls(h) if h else None
+
+    def fill_buffer(self, src):
+        src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, self.ninp)
+        return _L().fh_processor_fill_buffer(self.h, src.ctypes.data_as(C.c_void_p), src.shape[0])
+
+    def write_processed(self, count):
+        out = np.zeros((count, self.nout), np.float32)
+        _L().fh_processor_write_processed(self.h, out.ctypes.data_as(C.c_void_p), count)
+        return out
+
+    def pending_writes(self):
+        return _L().fh_processor_pending_writes(self.h)
+
+    def is_input_buffer_complete(self):
+        return bool(_L().fh_processor_is_input_buffer_complete(self.h))
+
+    def max_output_value(self):
+        return float(_L().fh_processor_max_output_value(self.h))
+
+    def max_abs_output_value(self):
+        return float(_L().fh_processor_max_abs_output_value(self.h))
+
+    def reset_max_values(self):
+        _L().fh_processor_reset_max_values(self.h)
+
+    def reset(self):
+        _L().fh_processor_reset(self.h)
+
+    def config_file(self):
+        return os.fsdecode(_L().fh_processor_config_file(self.h))
+
+    def config_file_timestamp(self):
+        return _L().fh_processor_config_file_timestamp(self.h)
+
+    def config_still_up_to_date(self):
+        return bool(_L().fh_processor_config_still_up_to_date(self.h))
+
+    def device(self):
+        return _L().fh_processor_device(self.h)
+
+    def run(self, x):
+        """The AddMoreSoundData loop (convolve-file-handler.cc:370-424, non-gapless)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.ninp)
+        outs, done = [], 0
+        while done < x.shape[0]:
+            r = self.fill_buffer(x[done:])
+            assert r > 0
+            outs.append(self.write_processed(r))
+            done += r
+        return np.concatenate(outs, 0) if outs else np.zeros((0, self.nout), np.float32)
+
+    def close(self):
+        if self.h and self.owned:
+            _L().fh_processor_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProcessorPool:
+    def __init__(self, max_per_config=3):
+        self.h = _L().fh_pool_create(max_per_config)
+
+    def get_or_create(self, base_dir, sampling_rate, channels, bits):
+        err = C.create_string_buffer(2048)
+        h = _L().fh_pool_get_or_create(self.h, os.fsencode(base_dir), sampling_rate, channels, bits, err, 2048)
+        if not h:
+            return None, err.value.decode(errors="replace")
+        return SoundProcessor(h, owned=False), ""
+
+    def give_back(self, proc):
+        """ProcessorPool::Return."""
+        if proc is None:
+            _L().fh_pool_return(self.h, None)
+            return
+        h, proc.h = proc.h, None
+        _L().fh_pool_return(self.h, h)
+
+    def pooled_count(self, config_path):
+        return _L().fh_pool_pooled_count(self.h, os.fsencode(config_path))
+
+    def close(self):
+        if self.h:
+            _L().fh_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

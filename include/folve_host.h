@@ -1,0 +1,71 @@
+/* folve_host.h — C view of the C++ host layer (headers under folve_amd/csrc/host).
+ *
+ * The host layer restates folve's SoundProcessor, ProcessorPool and config
+ * loader as C++ classes (namespace folve) above the engine ABI of
+ * folve_engine.h; a C++ caller — folve itself — uses those classes directly
+ * (INTEGRATION.md).  This header exposes the same objects to C / ctypes so that
+ * the parity tests can drive them exactly the way ConvolveFileHandler does.
+ * Each function names the reference member it forwards to.
+ */
+#ifndef FOLVE_HOST_H
+#define FOLVE_HOST_H
+
+#include "folve_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fh_processor fh_processor;   /* folve::SoundProcessor */
+typedef struct fh_pool fh_pool;             /* folve::ProcessorPool  */
+
+/* zita-sstring.cc:32 sstring() */
+int fh_sstring(const char *srce, char *dest, int size);
+
+/* zita-config.cc:282 config(): parse `config_file` into a new, uncommitted filter on
+ * `engine` (NULL: assemble on the host only).  Returns config()'s status; on
+ * return *filter is the filter (or NULL) and, if non-NULL, fragm/ninp/nout/size
+ * receive the ZitaConfig fields. */
+int fh_config_load(fe_engine *engine, const char *config_file, int fsamp, int channels,
+                   fe_filter **filter, int *fragm, int *ninp, int *nout, int *size);
+
+/* sound-processor.cc:34 SoundProcessor::Create (GPU chosen by the router); NULL on failure */
+fh_processor *fh_processor_create(const char *config_file, int samplerate, int channels);
+void fh_processor_destroy(fh_processor *p);
+/* FillBuffer (cc:76): reads min(frames_available, block - input_pos) frames from src; returns frames taken */
+int fh_processor_fill_buffer(fh_processor *p, const float *src, int frames_available);
+/* WriteProcessed (cc:86): processes if needed, copies sample_count frames to dst */
+void fh_processor_write_processed(fh_processor *p, float *dst, int sample_count);
+int fh_processor_is_input_buffer_complete(const fh_processor *p);
+int fh_processor_pending_writes(const fh_processor *p);
+int fh_processor_input_channels(const fh_processor *p);
+int fh_processor_output_channels(const fh_processor *p);
+int fh_processor_block_size(const fh_processor *p);
+float fh_processor_max_output_value(const fh_processor *p);
+float fh_processor_max_abs_output_value(const fh_processor *p);
+void fh_processor_reset_max_values(fh_processor *p);
+void fh_processor_reset(fh_processor *p);
+const char *fh_processor_config_file(const fh_processor *p);
+long long fh_processor_config_file_timestamp(const fh_processor *p);
+int fh_processor_config_still_up_to_date(const fh_processor *p);
+int fh_processor_device(const fh_processor *p);
+fe_stream *fh_processor_stream(const fh_processor *p);
+
+/* processor-pool.cc:33 ProcessorPool(max_per_config) */
+fh_pool *fh_pool_create(int max_per_config);
+void fh_pool_destroy(fh_pool *pool);
+/* GetOrCreate (cc:48): NULL on failure with the reference's message in errmsg */
+fh_processor *fh_pool_get_or_create(fh_pool *pool, const char *base_dir, int sampling_rate, int channels,
+                                    int bits, char *errmsg, int errmsg_size);
+/* Return (cc:93) */
+void fh_pool_return(fh_pool *pool, fh_processor *p);
+int fh_pool_pooled_count(fh_pool *pool, const char *config_path);
+
+/* the process-wide GPU sharder */
+int fh_router_device_count(void);
+int fh_router_live_streams(int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOLVE_HOST_H */
