@@ -1,0 +1,103 @@
+"""Materialise filter directories from tests/golden/*.npz (no access to /root/reference needed)."""
+import os
+import struct
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF_DEMO = "/root/reference/demo-filters"
+
+
+def write_wav(path, data, rate=44100, fmt="pcm16"):
+    """data: [frames, ch]; int16 for pcm16, float for the others."""
+    data = np.asarray(data)
+    if data.ndim == 1:
+        data = data[:, None]
+    ch = data.shape[1]
+    if fmt == "pcm16":
+        raw, tag, bits = data.astype("<i2").tobytes(), 1, 16
+    elif fmt == "pcm24":
+        v = np.clip(np.round(data * 8388608.0), -8388608, 8388607).astype(np.int32)
+        b = v.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]
+        raw, tag, bits = b.tobytes(), 1, 24
+    elif fmt == "pcm32":
+        raw, tag, bits = np.clip(np.round(data * 2147483648.0), -2**31, 2**31 - 1).astype("<i4").tobytes(), 1, 32
+    elif fmt == "float32":
+        raw, tag, bits = data.astype("<f4").tobytes(), 3, 32
+    elif fmt == "pcm8":
+        raw, tag, bits = np.clip(np.round(data * 128.0) + 128, 0, 255).astype(np.uint8).tobytes(), 1, 8
+    else:
+        raise ValueError(fmt)
+    align = ch * bits // 8
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(raw), b"WAVE", b"fmt ", 16, tag, ch, rate,
+                      rate * align, align, bits, b"data", len(raw))
+    with open(path, "wb") as f:
+        f.write(hdr + raw)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, "demo_%s.npz" % name))
+
+
+def make_pass_filter_dir(tmp, name):
+    """lowpass / highpass demo filter rebuilt from the golden taps: same WAV shape
+    (65536-frame 16-bit stereo, zeros after the taps), same commands."""
+    g = golden(name)
+    d = os.path.join(str(tmp), name)
+    os.makedirs(d, exist_ok=True)
+    wav = np.zeros((int(g["wav_frames"]), 2), np.int16)
+    taps = g["taps_int16"]
+    wav[: len(taps)] = taps
+    write_wav(os.path.join(d, "%s_44.wav" % name), wav, int(g["wav_rate"]))
+    gain = {"lowpass": "0.75", "highpass": "0.55"}[name]
+    with open(os.path.join(d, "filter-44100.conf"), "w") as f:
+        f.write("#                 in  out     partition    maxsize\n")
+        f.write("/convolver/new    2    2        1024        65536\n\n")
+        f.write("/impulse/read    1   1  %s    0      0       0       1     %s_44.wav\n" % (gain, name))
+        f.write("/impulse/read    2   2  %s    0      0       0       1     %s_44.wav\n#\n" % (gain, name))
+    return d
+
+
+def make_echo_filter_dir(tmp):
+    g = golden("echo")
+    d = os.path.join(str(tmp), "echo")
+    os.makedirs(d, exist_ok=True)
+    for rate, delay in ((44100, int(g["delay_44100"])), (192000, int(g["delay_192000"]))):
+        with open(os.path.join(d, "filter-%d.conf" % rate), "w") as f:
+            f.write("/convolver/new    2    2         256     204800        0.5\n")
+            f.write("/impulse/dirac   1   1   0.7       0\n/impulse/dirac   2   2   0.7       0\n")
+            f.write("/impulse/dirac   1   1   0.3       %d\n/impulse/dirac   2   2   0.3       %d\n" % (delay, delay))
+    return d
+
+
+def make_santalucia_shaped_dir(tmp, seed=2):
+    """A synthetic IR with the shape of the SantaLucia demo (2 paths, 178193 taps at
+    delay 500 from offset 1400 of a 179593-frame file, + dirac 0.4 @0, size 204800).
+    Returns (dir, {(i,o): dense float32 h})."""
+    g = golden("santalucia")
+    frames, size, delay, offset = int(g["wav_frames"]), int(g["size"]), int(g["delay"]), int(g["offset"])
+    rng = np.random.default_rng(seed)
+    env = np.exp(-np.arange(frames) / 40000.0)
+    ir = rng.standard_normal((frames, 2)) * env[:, None]
+    ir = ir / np.abs(ir).max() * 0.9
+    wav = np.round(ir * 32767).astype(np.int16)
+    d = os.path.join(str(tmp), "SantaLuciaShaped")
+    os.makedirs(d, exist_ok=True)
+    write_wav(os.path.join(d, "ir.wav"), wav, 44100)
+    with open(os.path.join(d, "filter-44100.conf"), "w") as f:
+        f.write("/convolver/new    2    2         256     %d        0.5\n" % size)
+        f.write("/impulse/read    1   1   4e-3     %d    %d       0    1   ir.wav\n" % (delay, offset))
+        f.write("/impulse/read    2   2   4e-3     %d    %d       0    2   ir.wav\n" % (delay, offset))
+        f.write("/impulse/dirac   1   1   0.4       0\n/impulse/dirac   2   2   0.4       0\n")
+    hs = {}
+    n = frames - offset
+    for c in range(2):
+        h = np.zeros(size, np.float32)
+        h[delay:delay + n] += np.float32(4e-3) * (wav[offset:, c].astype(np.float32) / np.float32(32768.0))
+        h[0] += np.float32(0.4)
+        hs[(c, c)] = h
+    return d, hs
+
+
+def seeded_input(seed, frames, ch):
+    return np.random.default_rng(seed).uniform(-1, 1, (frames, ch)).astype(np.float32)

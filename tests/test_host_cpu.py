@@ -1,0 +1,244 @@
+"""CPU: the product's host logic that needs no GPU — C-ABI surface, config loader, path choice."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import folve_amd as fa
+from folve_amd import host as H
+from fixtures import (REF_DEMO, golden, make_echo_filter_dir, make_pass_filter_dir, make_santalucia_shaped_dir,
+                      write_wav)
+from test_oracle_cpu import SSTRING_CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = fa.lib()
+    declared = set()
+    for hdr in ("folve_engine.h", "folve_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(f[eh]_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 55
+    from folve_amd.capi import ENGINE_SYMBOLS
+    bound = {n for n, _, _ in ENGINE_SYMBOLS} | {n for n, _, _ in H.HOST_SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_cpu_fallback_fails_loudly():
+    if fa.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(fa.FolveError) as ei:
+        fa.Engine(0)
+    assert ei.value.code == -4
+    flt = fa.Filter(None, 1, 1, 100)
+    flt.add(0, 0, [1.0])
+    with pytest.raises(fa.FolveError):
+        flt.commit()
+    assert H.SoundProcessor.create(os.path.join(ROOT, "tests", "nonexistent.conf"), 44100, 2) is None
+
+
+def test_product_never_links_the_oracle():
+    so = fa.lib_path()
+    out = os.popen("readelf -d %s" % so).read()
+    assert "liboracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "folve_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hpp", ".hip")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                for needle in ("import oracle", "from oracle", "liboracle", "oracle_", "oracle."):
+                    assert needle not in txt, (f, needle)
+
+
+@pytest.mark.parametrize("size", [1024, 8, 1, 0])
+def test_host_sstring_equals_oracle(oracle, size):
+    rng = np.random.default_rng(1)
+    alphabet = b"ab \t'\"\\\n\x00x"
+    cases = list(SSTRING_CASES) + [bytes(rng.choice(list(alphabet), rng.integers(1, 12))) for _ in range(2000)]
+    for src in cases:
+        assert H.sstring(src, size) == oracle.sstring(src, size), (src, size)
+
+
+def test_filter_limits_and_block_size():
+    assert fa.fragm_for_size(100) == 128 and fa.fragm_for_size(4097) == 8192 and fa.fragm_for_size(1) == 64
+    for bad in [(0, 1, 100), (65, 1, 100), (1, 0, 100), (1, 65, 100), (1, 1, 0), (1, 1, 0x100001)]:
+        with pytest.raises(fa.FolveError):
+            fa.Filter(None, *bad)
+    f = fa.Filter(None, 64, 64, 0x100000)
+    assert f.block_size == 8192 and f.partitions == 128
+    with pytest.raises(fa.FolveError):
+        f.add(64, 0, [1.0])
+    with pytest.raises(fa.FolveError):
+        f.link(0, 0, 0, 0)
+    f.link(0, 0, 1, 1)
+    with pytest.raises(fa.FolveError):
+        f.link(1, 1, 0, 0)              # cycle
+
+
+def test_accumulate_link_and_masks():
+    f = fa.Filter(None, 2, 2, 30000)
+    f.add(0, 0, np.ones(10, np.float32), 8190)          # straddles partitions 0 and 1
+    f.add(0, 0, np.full(5, 2.0, np.float32), 8192)
+    f.add(0, 0, [9.0], 29999)
+    f.add(0, 0, [7.0, 7.0, 7.0], 32767)                 # beyond K*P = 32768: clipped
+    f.link(0, 0, 1, 1)
+    f.add(1, 1, [0.5], 0)                               # addition through the link lands in the shared data
+    t = f.taps(0, 0)
+    assert t[8190] == 1 and t[8192] == 3 and t[8197] == 1 and t[29999] == 9 and t[32767] == 7 and t[0] == 0.5
+    assert np.array_equal(f.taps(1, 1), t)
+    assert f.path_partitions(0, 0) == 3 and f.path_partitions(1, 0) == 0   # partitions 0, 1 and 3
+    # strided source (zita-config.cc:163 passes step = nchan)
+    g = fa.Filter(None, 1, 1, 100)
+    g.add(0, 0, np.arange(10, dtype=np.float32), 3, step=2)
+    assert np.array_equal(g.taps(0, 0)[3:8], [0, 2, 4, 6, 8])
+
+
+@pytest.mark.parametrize("name", ["lowpass", "highpass"])
+def test_loader_assembles_pass_filters_bit_exactly(tmp_path, name):
+    g = golden(name)
+    d = make_pass_filter_dir(tmp_path, name)
+    st, flt, z = H.config_load(os.path.join(d, "filter-44100.conf"))
+    assert st == 0 and z == {"fragm": 8192, "ninp": 2, "nout": 2, "size": 65536}
+    taps = g["taps_int16"]
+    h = np.zeros(65536, np.float32)
+    h[: len(taps)] = np.float32(g["gain"]) * (taps[:, 0].astype(np.float32) / np.float32(32768.0))
+    for c in range(2):              # both outputs use file channel 1
+        assert np.array_equal(flt.taps(c, c), h)
+    assert flt.path_partitions(0, 0) == 8 and flt.path_partitions(0, 1) == 0   # zeros still populate partitions
+    assert float(h.astype(np.float64).sum()) == pytest.approx(float(g["h_sum"]), abs=1e-9)
+
+
+def test_loader_santalucia_semantics(tmp_path):
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    st, flt, z = H.config_load(os.path.join(d, "filter-44100.conf"))
+    assert st == 0 and z["size"] == 204800 and flt.partitions == 25
+    for c in range(2):
+        assert np.array_equal(flt.taps(c, c, 204800), hs[(c, c)])      # delay 500, offset 1400, dirac accumulates
+        assert flt.path_partitions(c, c) == 22
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DEMO), reason="needs /root/reference")
+def test_loader_on_the_reference_demo_filters():
+    g = golden("santalucia")
+    st, flt, z = H.config_load(os.path.join(REF_DEMO, "SantaLucia", "filter-44100.conf"))
+    assert st == 0
+    for c in range(2):
+        h = flt.taps(c, c, 204800)
+        assert np.array_equal(h[g["h_probe_idx"]], g["h_probe"][c])
+        assert float(h.astype(np.float64).sum()) == pytest.approx(float(g["h_sum"][c]), rel=1e-12)
+        assert float(np.linalg.norm(h.astype(np.float64))) == pytest.approx(float(g["h_l2"][c]), rel=1e-12)
+        assert np.flatnonzero(h)[-1] <= int(g["last_tap"])
+    assert flt.path_partitions(0, 0) == 22
+    for name, k in (("echo", 2), ("lowpass", 8), ("highpass", 8)):
+        st, flt, _ = H.config_load(os.path.join(REF_DEMO, name, "filter-44100.conf"))
+        assert st == 0 and flt.path_partitions(0, 0) == k and flt.path_partitions(1, 0) == 0
+
+
+def _conf(tmp_path, text, name="filter-44100.conf"):
+    p = os.path.join(str(tmp_path), name)
+    with open(p, "w") as f:
+        f.write(text)
+    return p
+
+
+def test_loader_grammar_errors_and_commands(tmp_path, oracle):
+    new = "/convolver/new 2 2 256 20000\n"
+    cases = [
+        ("garbage line\n", H.ERR_SYNTAX),
+        ("   # comment only\n\n" + new, 0),
+        (new + "/bogus/command 1\n", H.ERR_COMMAND),
+        ("/impulse/dirac 1 1 0.5 0\n", H.ERR_NOCONV),
+        (new + "/impulse/dirac 3 1 0.5 0\n", H.ERR_IONUM),
+        (new + "/impulse/dirac 1 1 0.5\n", H.ERR_PARAM),
+        (new + "/impulse/copy 1 1 1 1\n", H.ERR_PARAM),
+        (new + "/impulse/hilbert 1 1 1.0 100 32\n", H.ERR_PARAM),        # length < 64
+        (new + "/impulse/read 1 1 1.0 0 0 0 1 missing.wav\n", 0),        # ERR_OTHER is swallowed
+        ("/convolver/new 2 2 256\n", H.ERR_PARAM),
+        ("/convolver/new 99 2 256 1000\n", 0),                           # out of range -> ERR_OTHER -> 0, no filter
+        (new + "/input/name 1 in.L\n/output/name 2 out.R\n", 0),
+        (new + "/cd\n", H.ERR_PARAM),
+    ]
+    for i, (text, want) in enumerate(cases):
+        p = _conf(tmp_path, text, "c%d.conf" % i)
+        st, flt, _ = H.config_load(p)
+        assert st == want, (text, st)
+        # the oracle restatement agrees on every status
+        sp_ok = oracle.SoundProcessor.create(p, 44100, 2) is not None
+        assert sp_ok == (st == 0 and flt is not None), text
+    st, flt, _ = H.config_load(os.path.join(str(tmp_path), "does-not-exist.conf"))
+    assert st == -1 and flt is None
+
+
+def test_loader_hilbert_copy_cd_quoting_and_formats(tmp_path, oracle):
+    sub = os.path.join(str(tmp_path), "ir dir")
+    os.makedirs(sub)
+    rng = np.random.default_rng(4)
+    ir = rng.uniform(-0.5, 0.5, (3000, 3))
+    write_wav(os.path.join(sub, "f32.wav"), ir, 48000, "float32")
+    write_wav(os.path.join(sub, "p24.wav"), ir, 44100, "pcm24")
+    write_wav(os.path.join(sub, "p32.wav"), ir, 44100, "pcm32")
+    write_wav(os.path.join(sub, "p8.wav"), ir, 44100, "pcm8")
+    text = ("/convolver/new 2 3 512 16000 0.3\n"
+            "/cd \"ir dir\"\n"
+            "/impulse/read 1 1 0.5 10 100 1000 3 f32.wav\n"          # rate mismatch is only logged
+            "/impulse/read 1 1 0.25 20 0 0 1 'p24.wav'\n"             # accumulates onto the same pair
+            "/impulse/read 2 2 1.0 0 2990 500 2 p32.wav\n"            # length beyond EOF: ends at EOF
+            "/impulse/read 2 3 1.0 15990 0 0 1 p8.wav\n"              # truncated to size - delay
+            "/impulse/hilbert 2 1 0.8 300 256\n"
+            "/impulse/hilbert 2 1 0.8 100 256\n"                      # delay < length/2: skipped
+            "/impulse/dirac 2 1 0.1 16000\n"                          # delay >= size: ignored
+            "/impulse/copy 1 3 1 1\n")
+    p = _conf(tmp_path, text)
+    st, flt, z = H.config_load(p)
+    assert st == 0 and z["ninp"] == 2 and z["nout"] == 3 and flt.block_size == 8192
+    f32 = ir.astype(np.float32)
+    h11 = np.zeros(16000, np.float32)
+    h11[10:1010] += f32[100:1100, 2] * np.float32(0.5)
+    p24 = (np.clip(np.round(ir * 8388608.0), -8388608, 8388607).astype(np.int32) * 256).astype(np.float32) / np.float32(2147483648.0)
+    h11[20:3020] += p24[:, 0] * np.float32(0.25)
+    assert np.array_equal(flt.taps(0, 0, 16000), h11)
+    assert np.array_equal(flt.taps(0, 2, 16000), h11)                  # copy shares the data
+    p32 = np.clip(np.round(ir * 2147483648.0), -2**31, 2**31 - 1).astype(np.int32).astype(np.float32) / np.float32(2147483648.0)
+    h22 = np.zeros(16000, np.float32); h22[0:10] = p32[2990:3000, 1]
+    assert np.array_equal(flt.taps(1, 1, 16000), h22)
+    p8 = (np.clip(np.round(ir * 128.0) + 128, 0, 255).astype(np.int32) - 128).astype(np.float32) / np.float32(128.0)
+    h23 = np.zeros(16000, np.float32); h23[15990:16000] = p8[:10, 0]
+    assert np.array_equal(flt.taps(1, 2, 16000), h23)
+    hil = flt.taps(1, 0, 16000)
+    nz = np.flatnonzero(hil)
+    assert nz.min() >= 300 - 128 and nz.max() < 300 + 128 and hil[300] == 0
+    assert np.allclose(hil[300 + 1], -hil[300 - 1]) and hil[300 - 1] > 0      # antisymmetric about the delay
+    # the oracle's loader builds the same convolver: compare impulse responses
+    sp = oracle.SoundProcessor.create(p, 44100, 2)
+    x = np.zeros((2 * 8192, 2), np.float32); x[0, 0] = 1.0
+    y = sp.run(x)
+    assert np.abs(y[:16000, 0] - h11).max() < 1e-6 and np.abs(y[:16000, 2] - h11).max() < 1e-6
+    x = np.zeros((2 * 8192, 2), np.float32); x[0, 1] = 1.0
+    y = sp.run(x)
+    assert np.abs(y[:16000, 0] - hil).max() < 1e-6 and np.abs(y[:16000, 1] - h22).max() < 1e-6
+    assert np.abs(y[:16000, 2] - h23).max() < 1e-6
+
+
+def test_pool_path_choice_and_error_strings(tmp_path):
+    d = make_echo_filter_dir(tmp_path)
+    pool = H.ProcessorPool(3)
+    p, err = pool.get_or_create(d, 48000, 2, 16)
+    assert p is None and err == "No filter in echo for 48.0kHz/2 ch/16 bits"
+    p, err = pool.get_or_create(d, 88200, 6, 24)
+    assert p is None and err == "No filter in echo for 88.2kHz/6 ch/24 bits"
+    if fa.device_count() == 0:
+        # most specific existing file wins: -R-C-B, then -R-C, then -R (processor-pool.cc:53-61)
+        open(os.path.join(d, "filter-44100-2.conf"), "w").write("garbage\n")
+        p, err = pool.get_or_create(d, 44100, 2, 16)
+        assert p is None and err == "Problem parsing " + os.path.join(d, "filter-44100-2.conf")
+        open(os.path.join(d, "filter-44100-2-16.conf"), "w").write("garbage\n")
+        p, err = pool.get_or_create(d, 44100, 2, 16)
+        assert p is None and err == "Problem parsing " + os.path.join(d, "filter-44100-2-16.conf")
+        p, err = pool.get_or_create(d, 44100, 2, 24)
+        assert err == "Problem parsing " + os.path.join(d, "filter-44100-2.conf")
+    pool.give_back(None)        # Return(NULL) is a no-op

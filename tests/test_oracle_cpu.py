@@ -1,0 +1,151 @@
+"""CPU: pin the oracle — against the float64 definition of the path, the closed forms and
+golden vectors of the reference's demo filters, and the one reference TU that compiles here."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from fixtures import (REF_DEMO, golden, make_echo_filter_dir, make_pass_filter_dir, make_santalucia_shaped_dir,
+                      seeded_input)
+
+TOL = 1e-5
+HAVE_REF = os.path.isdir(REF_DEMO)
+
+
+@pytest.mark.parametrize("size,fragm", [(1, 64), (32, 64), (33, 64), (64, 64), (65, 128), (100, 128), (128, 128),
+                                        (129, 256), (256, 256), (257, 512), (512, 512), (2048, 2048), (2049, 4096),
+                                        (4096, 4096), (4097, 8192), (65536, 8192), (0x100000, 8192)])
+def test_fragm_derivation_table(oracle, size, fragm):
+    """zita-fconfig.cc:74-77: fragm = 8192; while (fragm > 64 && fragm >= 2*size) fragm /= 2."""
+    assert oracle.fragm_for_size(size) == fragm
+
+
+@pytest.mark.parametrize("size,nframes", [(100, 1000), (3000, 20000), (20000, 40000), (70000, 5 * 8192 + 123)])
+def test_oracle_matches_float64_linear_convolution(oracle, size, nframes):
+    rng = np.random.default_rng(size)
+    h = {(0, 0): (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32),
+         (1, 1): (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32),
+         (0, 1): (rng.standard_normal(size // 2) / np.sqrt(size)).astype(np.float32)}
+    c = oracle.Convproc(2, 2, size)
+    for (i, o), t in h.items():
+        c.impdata_create(i, o, t, 0)
+    sp = oracle.SoundProcessor.wrap(c)
+    x = rng.uniform(-1, 1, (nframes, 2)).astype(np.float32)
+    y = sp.run(x)
+    ref = oracle.linear_convolution_f64(x, h, 2)
+    assert oracle.rms(y - ref) <= TOL
+    assert oracle.rms(y - ref) / oracle.rms(ref) <= TOL
+    assert sp.max_output_value() == pytest.approx(max(0.0, float(y.max())), abs=1e-7)
+
+
+def test_impulse_in_gives_h_out_and_link_equals_duplicate(oracle):
+    rng = np.random.default_rng(1)
+    size = 10000
+    h = (rng.standard_normal(size) * 0.1).astype(np.float32)
+    a = oracle.Convproc(1, 2, size)
+    a.impdata_create(0, 0, h, 0)
+    a.impdata_copy(0, 0, 0, 1)               # (0,1) shares (0,0)
+    a.impdata_create(0, 0, np.float32([0.5]), 17)   # later addition to the source is shared too
+    b = oracle.Convproc(1, 2, size)
+    for o in (0, 1):
+        b.impdata_create(0, o, h, 0)
+        b.impdata_create(0, o, np.float32([0.5]), 17)
+    x = np.zeros((2 * 8192, 1), np.float32)
+    x[0] = 1.0
+    ya = oracle.SoundProcessor.wrap(a).run(x)
+    yb = oracle.SoundProcessor.wrap(b).run(x)
+    hh = h.copy(); hh[17] += 0.5
+    assert np.abs(ya[:size, 0] - hh).max() < 1e-6
+    assert np.array_equal(ya[:, 0], ya[:, 1])
+    assert np.abs(ya - yb).max() < 1e-6
+
+
+def test_reset_and_partial_block_semantics(oracle):
+    rng = np.random.default_rng(2)
+    h = (rng.standard_normal(9000) * 0.05).astype(np.float32)
+    c = oracle.Convproc(1, 1, 9000)
+    c.impdata_create(0, 0, h, 0)
+    sp = oracle.SoundProcessor.wrap(c)
+    x = rng.uniform(-1, 1, (8192 + 500, 1)).astype(np.float32)
+    y1 = sp.run(x)
+    assert sp.pending_writes() == 8192 - 500 and not sp.is_input_buffer_complete()
+    sp.reset()
+    assert sp.max_output_value() == 0.0 and sp.pending_writes() == 0
+    assert np.array_equal(sp.run(x), y1)
+
+
+def test_echo_closed_form_from_golden(oracle, tmp_path):
+    g = golden("echo")
+    d = make_echo_filter_dir(tmp_path)
+    for rate, delay in ((44100, int(g["delay_44100"])), (192000, int(g["delay_192000"]))):
+        sp = oracle.SoundProcessor.create(os.path.join(d, "filter-%d.conf" % rate), rate, 2)
+        assert sp.fragm == 8192 and sp.path_partitions(0, 0) == 2 and sp.path_partitions(0, 1) == 0
+        x = seeded_input(5, delay + 2 * 8192 + 77, 2)
+        y = sp.run(x)
+        exp = float(g["gains"][0]) * x.astype(np.float64)
+        exp[delay:] += float(g["gains"][1]) * x[:-delay]
+        assert oracle.rms(y - exp) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["lowpass", "highpass"])
+def test_pass_filters_against_golden(oracle, tmp_path, name):
+    g = golden(name)
+    d = make_pass_filter_dir(tmp_path, name)
+    sp = oracle.SoundProcessor.create(os.path.join(d, "filter-44100.conf"), 44100, 2)
+    assert sp.fragm == 8192 and sp.path_partitions(0, 0) == 8 and sp.path_partitions(1, 1) == 8
+    x = seeded_input(int(g["seed"]), int(g["frames"]), 2)
+    y = sp.run(x)
+    assert oracle.rms(y[g["out_idx"]] - g["out_expected"]) <= TOL
+    assert oracle.rms(y[g["out_idx"]] - g["out_expected"]) / float(g["out_rms"]) <= TOL
+    if name == "highpass":      # DC in -> ~0 out once the taps are filled
+        dc = sp.__class__.create(os.path.join(d, "filter-44100.conf"), 44100, 2).run(np.ones((9000, 2), np.float32))
+        assert np.abs(dc[200:]).max() < 1e-3
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs /root/reference (authoring container only)")
+@pytest.mark.parametrize("name", ["lowpass", "highpass", "SantaLucia"])
+def test_reference_demo_files_against_golden(oracle, name):
+    """The same golden vectors, now through the reference's own .conf and .wav files."""
+    g = golden(name.lower())
+    sp = oracle.SoundProcessor.create(os.path.join(REF_DEMO, name, "filter-44100.conf"), 44100, 2)
+    x = seeded_input(int(g["seed"]), int(g["frames"]), 2)
+    y = sp.run(x)
+    assert oracle.rms(y[g["out_idx"]] - g["out_expected"]) <= TOL
+    if name == "SantaLucia":
+        assert sp.path_partitions(0, 0) == int(g["populated_partitions"]) == 22
+        assert sp.path_partitions(0, 1) == 0
+
+
+def test_santalucia_shaped_synthetic(oracle, tmp_path):
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    sp = oracle.SoundProcessor.create(os.path.join(d, "filter-44100.conf"), 44100, 2)
+    assert sp.path_partitions(0, 0) == 22 and sp.path_partitions(1, 1) == 22
+    x = seeded_input(9, 3 * 8192 + 11, 2)
+    y = sp.run(x)
+    assert oracle.rms(y - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+
+
+SSTRING_CASES = [b"plain rest", b"  lead", b'"quoted string" x', b"'single \\ quoted' y", b"esc\\ aped more",
+                 b'"unterminated', b"bad'quote", b'"mixed\' quote"', b"tab\tsep", b"\\", b"", b"   ", b'""', b"a\\\tb c",
+                 b"x\ny", b'"new\nline"', b"trail\\", b"'a\"b'", b"ab\"cd", b"\x01ctl", b"caf\xc3\xa9 x"]
+
+
+@pytest.mark.parametrize("size", [1024, 8, 4, 1, 0])
+def test_sstring_restatement_vs_reference_build(oracle, size):
+    """oracle/_ref/libref_sstring.so is /root/reference/zita-sstring.cc compiled where it lies."""
+    ref_so = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libref_sstring.so")
+    if not os.path.exists(ref_so):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    ref = C.CDLL(ref_so)._Z7sstringPKcPci
+    ref.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    rng = np.random.default_rng(0)
+    alphabet = b"ab \t'\"\\\n\x00x"
+    cases = list(SSTRING_CASES) + [bytes(rng.choice(list(alphabet), rng.integers(1, 12))) for _ in range(3000)]
+    for src in cases:
+        buf = C.create_string_buffer(b"\xff" * 1100, 1100)
+        n_ref = ref(src, buf, size)
+        n, val = oracle.sstring(src, size)
+        assert n == n_ref, (src, size, n, n_ref)
+        if n_ref:
+            assert val == buf.value, (src, size)
