@@ -87,16 +87,34 @@ FK_HD void dft(float2 (&v)[R]) {
 
 // ---- radix plan -----------------------------------------------------------
 // log2(N) -> up to four radices, product N.  13 (P = 8192) -> 16,16,8,4.
-struct Plan { int r[4]; int n; };
+struct Plan {
+    int r[4];       // radix of each pass
+    int ns[4];      // product of the earlier radices (twiddle period of the pass)
+    int off[4];     // offset of the pass's twiddle table in the per-P pass-twiddle buffer
+    int n;          // passes
+    int total;      // entries in the pass-twiddle buffer
+};
 constexpr Plan make_plan(int log2n) {
-    Plan p{{1, 1, 1, 1}, 0};
+    Plan p{{1, 1, 1, 1}, {1, 1, 1, 1}, {0, 0, 0, 0}, 0, 0};
     int left = log2n;
     while (left >= 4 && left != 5) { p.r[p.n++] = 16; left -= 4; }
     while (left >= 3) { p.r[p.n++] = 8; left -= 3; }
     if (left == 2) { p.r[p.n++] = 4; left = 0; }
     if (left == 1) { p.r[p.n++] = 2; left = 0; }
+    int ns = 1, off = 0;
+    for (int i = 0; i < p.n; ++i) {
+        p.ns[i] = ns;
+        p.off[i] = off;
+        if (ns > 1) off += (p.r[i] - 1) * ns;     // table[(r-1)*ns + k] = exp(-2*pi*i*k*r/(ns*R)), r = 1..R-1
+        ns *= p.r[i];
+    }
+    p.total = off;
     return p;
 }
+// Passes whose twiddle period is short read every row of their table (it stays in
+// L1); longer periods read only the power-of-two rows, coalesced, and form the
+// other powers as products (at most three factors).
+constexpr int kTableMaxPeriod = 64;
 
 // Threads per workgroup for an N-point transform: 16 points per thread, at
 // least one wavefront.
@@ -113,7 +131,7 @@ FK_HD int phys(int i) { return i + (i >> 4); }
 // One Stockham pass.  src(i) yields element i of the pass input (LDS or
 // global), dst(i, v) consumes element i of the pass output.  When the input is
 // the LDS image that dst overwrites, SYNC_AFTER_READ separates the phases.
-//   tw: exp(-2*pi*i*k/(2N)), k in [0, 2N)  (the table of the 2P-point real FFT)
+//   tw: this pass's table, tw[(r-1)*NS + k] = exp(-2*pi*i*k*r/(NS*R))
 template <int N, int NT, int R, int NS, bool INV, bool SYNC_AFTER_READ, class Src, class Dst>
 FK_D void stockham_pass(Src&& src, Dst&& dst, const float2* __restrict__ tw, int tid) {
     constexpr int NB = N / R;                       // butterflies in this pass
@@ -135,12 +153,24 @@ FK_D void stockham_pass(Src&& src, Dst&& dst, const float2* __restrict__ tw, int
         if (!GUARD || j < NB) {
             const int k = j & (NS - 1);
             if constexpr (NS > 1) {
-                constexpr int STEP = (2 * N) / (NS * R);
+                float2 w[R];                                  // w[r] = exp(-2*pi*i*k*r/(NS*R))
+                if constexpr (NS <= kTableMaxPeriod) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) {
-                    const float2 w = tw[k * r * STEP];
-                    v[c][r] = INV ? cmulc(v[c][r], w) : cmul(v[c][r], w);
+                    for (int r = 1; r < R; ++r) w[r] = tw[(r - 1) * NS + k];
+                } else {
+#pragma unroll
+                    for (int r = 1; r < R; r *= 2) w[r] = tw[(r - 1) * NS + k];
+#pragma unroll
+                    for (int r = 3; r < R; ++r) {
+                        if ((r & (r - 1)) != 0) {             // not a power of two: top bit * remainder
+                            int top = 1;
+                            while (top * 2 <= r) top *= 2;
+                            w[r] = cmul(w[top], w[r - top]);
+                        }
+                    }
                 }
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[c][r] = INV ? cmulc(v[c][r], w[r]) : cmul(v[c][r], w[r]);
             }
             dft<R, INV>(v[c]);
             const int j0 = (j - k) * R + k;
@@ -157,7 +187,7 @@ FK_D void stockham_pass(Src&& src, Dst&& dst, const float2* __restrict__ tw, int
 // the pass).  Callers put a __syncthreads() after this if `last` wrote LDS that
 // other threads will read.
 template <int LOG2N, bool INV, bool FIRST_IN_PLACE, bool LAST_IN_PLACE, class First, class Last>
-FK_D void fft_passes(float2* s, const float2* __restrict__ tw, int tid, First&& first, Last&& last) {
+FK_D void fft_passes(float2* s, const float2* __restrict__ ptw, int tid, First&& first, Last&& last) {
     constexpr int N = 1 << LOG2N;
     constexpr int NT = threads_for(N);
     constexpr Plan pl = make_plan(LOG2N);
@@ -165,20 +195,20 @@ FK_D void fft_passes(float2* s, const float2* __restrict__ tw, int tid, First&& 
     auto lds_dst = [&](int i, float2 v) { s[phys(i)] = v; };
     static_assert(pl.n >= 2 && pl.n <= 4, "plan");
     constexpr int R0 = pl.r[0], R1 = pl.r[1], R2 = pl.r[2], R3 = pl.r[3];
-    stockham_pass<N, NT, R0, 1, INV, FIRST_IN_PLACE>(first, lds_dst, tw, tid);
+    stockham_pass<N, NT, R0, 1, INV, FIRST_IN_PLACE>(first, lds_dst, ptw, tid);
     __syncthreads();
     if constexpr (pl.n == 2) {
-        stockham_pass<N, NT, R1, R0, INV, LAST_IN_PLACE>(lds_src, last, tw, tid);
+        stockham_pass<N, NT, R1, R0, INV, LAST_IN_PLACE>(lds_src, last, ptw + pl.off[1], tid);
     } else if constexpr (pl.n == 3) {
-        stockham_pass<N, NT, R1, R0, INV, true>(lds_src, lds_dst, tw, tid);
+        stockham_pass<N, NT, R1, R0, INV, true>(lds_src, lds_dst, ptw + pl.off[1], tid);
         __syncthreads();
-        stockham_pass<N, NT, R2, R0 * R1, INV, LAST_IN_PLACE>(lds_src, last, tw, tid);
+        stockham_pass<N, NT, R2, R0 * R1, INV, LAST_IN_PLACE>(lds_src, last, ptw + pl.off[2], tid);
     } else {
-        stockham_pass<N, NT, R1, R0, INV, true>(lds_src, lds_dst, tw, tid);
+        stockham_pass<N, NT, R1, R0, INV, true>(lds_src, lds_dst, ptw + pl.off[1], tid);
         __syncthreads();
-        stockham_pass<N, NT, R2, R0 * R1, INV, true>(lds_src, lds_dst, tw, tid);
+        stockham_pass<N, NT, R2, R0 * R1, INV, true>(lds_src, lds_dst, ptw + pl.off[2], tid);
         __syncthreads();
-        stockham_pass<N, NT, R3, R0 * R1 * R2, INV, LAST_IN_PLACE>(lds_src, last, tw, tid);
+        stockham_pass<N, NT, R3, R0 * R1 * R2, INV, LAST_IN_PLACE>(lds_src, last, ptw + pl.off[3], tid);
     }
 }
 

@@ -44,7 +44,8 @@ struct FilterDev {
     const uint32_t* mask;   // [ndata][4] populated-partition bitmap (K <= 128)
     const PathEntry* paths; // grouped by output channel
     const int* out_first;   // [cout + 1] prefix into paths
-    const float2* tw;       // exp(-2*pi*i*k/(2P)), k in [0, 2P)
+    const float2* tw;       // exp(-2*pi*i*k/(2P)), k in [0, P/2]   (real-FFT split / fold)
+    const float2* ptw;      // per-pass Stockham twiddles of the P-point FFT (fft_core.hpp: Plan::off)
 };
 
 // K1: PCM -> spectra.  grid (max blocks, cin, jobs)
@@ -57,6 +58,9 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
                           hipStream_t st);
 // K0: time-domain taps [ndata][K*P] -> H [ndata][K][P] (scaled by 1/(2P)).
 hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const float2* tw,
-                                   hipStream_t st);
+                                   const float2* ptw, hipStream_t st);
+// Host-side description of the pass-twiddle buffer for a P-point FFT.
+int pass_twiddle_count(int log2P);
+void fill_pass_twiddles(int log2P, float2* dst);   // dst[pass_twiddle_count(log2P)]
 
 }  // namespace fk

@@ -13,6 +13,10 @@
 //   K0 filter  : taps -> H spectra, 1/(2P) folded in (as zita folds 0.5/parsize)
 #include "kernels.h"
 
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "fft_core.hpp"
 
 namespace fk {
@@ -75,21 +79,30 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void forward_kernel(const 
     const float* __restrict__ in = job.in;
     const float2* __restrict__ tail_rd = reinterpret_cast<const float2*>(job.tail_rd + (size_t)c * P);
     float2* __restrict__ tail_wr = reinterpret_cast<float2*>(job.tail_wr + (size_t)c * P);
+    const bool wide2 = (cin == 2) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const bool wide1 = (cin == 1) && ((reinterpret_cast<uintptr_t>(in) & 7) == 0);
 
     auto load = [&](int m) -> float2 {
         float2 v;
         if (m < P / 2 && b == 0) {
             v = tail_rd[m];                               // block preceding this call
         } else {
-            const long long fr = f0 + 2 * m;
-            v.x = (fr < job.nframes) ? in[fr * cin + c] : 0.0f;
-            v.y = (fr + 1 < job.nframes) ? in[(fr + 1) * cin + c] : 0.0f;
+            const long long fr = f0 + 2 * m;                 // even: the pair never straddles a block
+            if (wide2 && fr + 1 < job.nframes) {             // stereo: one 16-byte load holds both frames
+                const float4 q = *reinterpret_cast<const float4*>(in + fr * 2);
+                v = (c == 0) ? float2{q.x, q.z} : float2{q.y, q.w};
+            } else if (wide1 && fr + 1 < job.nframes) {      // mono: the pair is contiguous
+                v = *reinterpret_cast<const float2*>(in + fr);
+            } else {
+                v.x = (fr < job.nframes) ? in[fr * cin + c] : 0.0f;
+                v.y = (fr + 1 < job.nframes) ? in[(fr + 1) * cin + c] : 0.0f;
+            }
             if (last && m >= P / 2) tail_wr[m - P / 2] = v;   // becomes the next call's x(n-1)
         }
         return v;
     };
     auto lds_dst = [&](int i, float2 v) { s[phys(i)] = v; };
-    fft_passes<LOG2P, false, false, true>(s, f.tw, tid, load, lds_dst);
+    fft_passes<LOG2P, false, false, true>(s, f.ptw, tid, load, lds_dst);
     __syncthreads();
     const int slot = ring_slot(job.slot0, b, job.ring);
     float2* row = job.fdl + ((size_t)c * job.ring + slot) * P;
@@ -102,14 +115,15 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void forward_kernel(const 
 template <int LOG2P>
 __global__ __launch_bounds__(threads_for(1 << LOG2P)) void filter_kernel(const float* __restrict__ taps,
                                                                          float2* __restrict__ H, int K,
-                                                                         const float2* __restrict__ tw) {
+                                                                         const float2* __restrict__ tw,
+                                                                         const float2* __restrict__ ptw) {
     constexpr int P = 1 << LOG2P;
     __shared__ float2 s[lds_elems(P)];
     const int j = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const float2* __restrict__ part = reinterpret_cast<const float2*>(taps + ((size_t)d * K + j) * P);
     auto load = [&](int m) -> float2 { return (m < P / 2) ? part[m] : float2{0.0f, 0.0f}; };   // [h_j | 0]
     auto lds_dst = [&](int i, float2 v) { s[phys(i)] = v; };
-    fft_passes<LOG2P, false, false, true>(s, tw, tid, load, lds_dst);
+    fft_passes<LOG2P, false, false, true>(s, ptw, tid, load, lds_dst);
     __syncthreads();
     split_and_store<LOG2P>(s, tw, tid, H + ((size_t)d * K + j) * P, 0.5f / (float)P);
 }
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const 
     __syncthreads();
 
     float* __restrict__ out = job.out;
+    const bool wide1 = (cout == 1) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
     const long long fb = (long long)b * P;
     float pk_s = 0.0f, pk_a = 0.0f;
     auto lds_src = [&](int i) { return s[phys(i)]; };
@@ -159,6 +174,12 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const 
     auto store = [&](int q, float2 z) {
         if (q >= P / 2) {
             const long long fr = fb + 2 * q - P;
+            if (wide1 && fr + 1 < job.nframes) {             // mono: the pair is contiguous
+                *reinterpret_cast<float2*>(out + fr) = z;
+                pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
+                pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
+                return;
+            }
             if (fr < job.nframes) {
                 out[fr * cout + o] = z.x;
                 pk_s = fmaxf(pk_s, z.x);
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const 
             }
         }
     };
-    fft_passes<LOG2P, true, true, false>(s, tw, tid, lds_src, store);
+    fft_passes<LOG2P, true, true, false>(s, f.ptw, tid, lds_src, store);
 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -183,6 +204,35 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const 
         atomicMax(job.peaks + 0, __float_as_uint(pk_s));
         atomicMax(job.peaks + 1, __float_as_uint(pk_a));
     }
+}
+
+
+// Packed bin 0 = (DC, Nyquist): two real products, not a complex one.  Done by
+// the first TT threads of the workgroup that owns bin 0, one output block each.
+template <int TT>
+__device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const FilterDev& f, float2* __restrict__ Y,
+                                                int t0, int pe0, int pe1, size_t yrow0) {
+    if (blockIdx.x != 0 || (int)threadIdx.x >= TT || t0 + (int)threadIdx.x >= job.nblocks) return;
+    const int P = f.P, K = f.K, ring = job.ring;
+    const int tt = threadIdx.x;
+    float re = 0.f, im = 0.f;
+    for (int pe = pe0; pe < pe1; ++pe) {
+        const PathEntry pth = f.paths[pe];
+        const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
+        const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
+        const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
+        const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
+        for (int j = K - 1; j >= 0; --j) {
+            const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
+            if (!on) continue;
+            const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
+            const float2 x = X[(size_t)slot * P];
+            const float2 h = Hd[(size_t)j * P];
+            re = fmaf(x.x, h.x, re);
+            im = fmaf(x.y, h.y, im);
+        }
+    }
+    Y[(yrow0 + tt) * P] = float2{re, im};
 }
 
 // ---------------------------------------------------------------------------
@@ -237,29 +287,101 @@ __global__ __launch_bounds__(256) void mac_kernel(const StreamJob* __restrict__ 
             else reinterpret_cast<float4*>(row)[bp] = acc[tt];
         }
     }
-    // Packed bin 0 = (DC, Nyquist): two real products, not a complex one.
-    if (blockIdx.x == 0 && threadIdx.x < TT && t0 + (int)threadIdx.x < job.nblocks) {
-        const int tt = threadIdx.x;
-        float re = 0.f, im = 0.f;
-        for (int pe = pe0; pe < pe1; ++pe) {
-            const PathEntry pth = f.paths[pe];
-            const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
-            const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
-            const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
-            const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
-            // same accumulation order as the main loop: oldest input block first
-            for (int j = K - 1; j >= 0; --j) {
-                const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
-                if (!on) continue;
-                const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
-                const float2 x = X[(size_t)slot * P];
-                const float2 h = Hd[(size_t)j * P];
-                re = fmaf(x.x, h.x, re);
-                im = fmaf(x.y, h.y, im);
+    mac_packed_bin0<TT>(job, f, Y, t0, pe0, pe1, yrow0);
+}
+
+// ---------------------------------------------------------------------------
+// K2, dense fast path: sliding-window MAC.  Per bin the work is a length-K FIR
+// along time, Y(t) = sum_j X(t-j) H(j).  Each thread keeps TT accumulators and a
+// TT-deep window of X in registers; per step j it loads ONE H row element and
+// ONE new X row element and issues TT complex MACs.  The window is a circular
+// buffer whose slot index (tt - j) mod TT is static because the j loop is
+// unrolled by TT — no register moves, no re-loads of H.
+//   HBM bytes per output block and bin: 8*(K+TT)/TT (X) + 8 (Y) + H via L2.
+// ---------------------------------------------------------------------------
+template <int NB> struct BinVec;
+template <> struct BinVec<1> { using type = float2; };
+template <> struct BinVec<2> { using type = float4; };
+
+__device__ __forceinline__ void cmacv(float2& acc, const float2& x, const float2& h) {
+    acc.x = fmaf(x.x, h.x, acc.x); acc.x = fmaf(-x.y, h.y, acc.x);
+    acc.y = fmaf(x.x, h.y, acc.y); acc.y = fmaf(x.y, h.x, acc.y);
+}
+__device__ __forceinline__ void cmacv(float4& acc, const float4& x, const float4& h) { cmac2(acc, x, h); }
+__device__ __forceinline__ void vzero(float2& v) { v = float2{0.f, 0.f}; }
+__device__ __forceinline__ void vzero(float4& v) { v = float4{0.f, 0.f, 0.f, 0.f}; }
+
+template <int TT, int NB, int D>
+__global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+                                                        float2* __restrict__ Y, int tiles) {
+    using V = typename BinVec<NB>::type;
+    const StreamJob job = jobs[blockIdx.z];
+    const int o = blockIdx.y / tiles;
+    const int t0 = (blockIdx.y - o * tiles) * TT;
+    if (t0 >= job.nblocks) return;
+    const int P = f.P, K = f.K, ring = job.ring;
+    const size_t PV = (size_t)(P / NB);                     // vectors per spectrum row
+    const int bv = blockIdx.x * blockDim.x + threadIdx.x;   // this thread's vector within a row
+    V acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) vzero(acc[tt]);
+
+    const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
+    for (int pe = pe0; pe < pe1; ++pe) {
+        const PathEntry pth = f.paths[pe];
+        const V* __restrict__ Hd = reinterpret_cast<const V*>(f.H + (size_t)pth.data * K * P) + bv;
+        const V* __restrict__ X = reinterpret_cast<const V*>(job.fdl + (size_t)pth.in_ch * ring * P) + bv;
+        const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
+        const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
+        V xw[TT];                                           // slot q holds X(t0 + q') with q' == q (mod TT)
+#pragma unroll
+        for (int q = 0; q < TT; ++q) xw[q] = X[(size_t)ring_slot(job.slot0, t0 + q, ring) * PV];
+        // software pipeline, D steps deep: the H and X elements of step j+D are
+        // requested at step j (keeps >= 40 KB per CU in flight at 2-4 waves/SIMD)
+        static_assert(TT % D == 0, "prefetch ring must divide the unroll");
+        V hq[D], xq[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < K) {
+                hq[d] = Hd[(size_t)d * PV];
+                xq[d] = X[(size_t)ring_slot(job.slot0, t0 - d - 1, ring) * PV];
             }
         }
-        Y[(yrow0 + tt) * P] = float2{re, im};
+        for (int j0 = 0; j0 < K; j0 += TT) {
+#pragma unroll
+            for (int jj = 0; jj < TT; ++jj) {
+                const int j = j0 + jj;
+                if (j < K) {
+                    const V h = hq[jj % D];
+                    const V xnew = xq[jj % D];
+                    if (j + D < K) {
+                        hq[jj % D] = Hd[(size_t)(j + D) * PV];
+                        xq[jj % D] = X[(size_t)ring_slot(job.slot0, t0 - j - D - 1, ring) * PV];
+                    }
+                    const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
+                    if (on) {
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) cmacv(acc[tt], xw[(tt - jj) & (TT - 1)], h);
+                    }
+                    xw[(TT - 1 - jj) & (TT - 1)] = xnew;    // X(t0 - j - 1): needed from step j+1 on
+                }
+            }
+        }
     }
+    const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * job.nblocks + t0;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        if (t0 + tt < job.nblocks) {
+            float2* row = Y + (yrow0 + tt) * P;
+            if constexpr (NB == 2) {
+                if (bv == 0) row[1] = float2{acc[tt].z, acc[tt].w};   // bin 0 is packed: written below
+                else reinterpret_cast<float4*>(row)[bv] = acc[tt];
+            } else {
+                if (bv != 0) row[bv] = acc[tt];
+            }
+        }
+    }
+    mac_packed_bin0<TT>(job, f, Y, t0, pe0, pe1, yrow0);
 }
 
 template <template <int> class Fn, class... A>
@@ -296,9 +418,10 @@ struct InvLaunch {
 };
 template <int L>
 struct FilterLaunch {
-    static hipError_t run(const float* taps, float2* H, int ndata, int K, const float2* tw, hipStream_t st) {
+    static hipError_t run(const float* taps, float2* H, int ndata, int K, const float2* tw, const float2* ptw,
+                          hipStream_t st) {
         dim3 grid(K, ndata), block(threads_for(1 << L));
-        hipLaunchKernelGGL(filter_kernel<L>, grid, block, 0, st, taps, H, K, tw);
+        hipLaunchKernelGGL(filter_kernel<L>, grid, block, 0, st, taps, H, K, tw, ptw);
         return hipGetLastError();
     }
 };
@@ -315,13 +438,59 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
 }
 
 hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const float2* tw,
-                                   hipStream_t st) {
-    return dispatch_log2p<FilterLaunch>(log2P, taps, H, ndata, K, tw, st);
+                                   const float2* ptw, hipStream_t st) {
+    return dispatch_log2p<FilterLaunch>(log2P, taps, H, ndata, K, tw, ptw, st);
 }
 
+int pass_twiddle_count(int log2P) { return make_plan(log2P).total; }
+
+void fill_pass_twiddles(int log2P, float2* dst) {
+    const Plan pl = make_plan(log2P);
+    for (int p = 1; p < pl.n; ++p) {
+        const int R = pl.r[p], NS = pl.ns[p];
+        for (int r = 1; r < R; ++r)
+            for (int k = 0; k < NS; ++k) {
+                const double a = -2.0 * M_PI * (double)k * (double)r / ((double)NS * (double)R);
+                dst[pl.off[p] + (r - 1) * NS + k] = float2{(float)cos(a), (float)sin(a)};
+            }
+    }
+}
+
+// Variant choice: the sliding-window kernel when the call carries >= 4 blocks per
+// stream (run-ahead batches); the generic kernel for short calls (a single block is
+// a pure stream over K rows and is already HBM-bound).  FOLVE_AMD_MAC=generic|s4|s8|s16|s32
+// overrides for experiments.
 hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, float2* Y, int time_tile,
                       hipStream_t st) {
+    static const char* force = getenv("FOLVE_AMD_MAC");
     const int P2 = f.P / 2;
+    int variant = 0, nb = 2, depth = 2;    // variant: 0 generic, else TT of the slide kernel
+    if (force && force[0] == 's') {
+        variant = atoi(force + 1);
+        if (strstr(force, "n1")) nb = 1;
+        const char* d = strchr(force, 'd');
+        if (d) depth = atoi(d + 1);
+    } else if (!force) {
+        if (time_tile >= 12) { variant = 16; nb = 1; depth = 4; }
+        else if (time_tile >= 6) { variant = 8; nb = 2; depth = 2; }
+        else if (time_tile >= 4) { variant = 4; nb = 2; depth = 2; }
+    }
+    if (variant && f.P / nb < 64) variant = 0;
+    if (variant) {
+        const int pv = f.P / nb;
+        const int nt = pv < 256 ? pv : 256;
+        const int tiles = (max_blocks + variant - 1) / variant;
+        dim3 grid(pv / nt, f.cout * tiles, njobs), block(nt);
+#define FK_SLIDE(TTv, NBv, Dv)                                                                              \
+    if (variant == TTv && nb == NBv && depth == Dv) {                                                       \
+        hipLaunchKernelGGL((mac_slide_kernel<TTv, NBv, Dv>), grid, block, 0, st, jobs, f, Y, tiles);        \
+        return hipGetLastError();                                                                           \
+    }
+        FK_SLIDE(4, 2, 2) FK_SLIDE(8, 2, 2) FK_SLIDE(8, 2, 4) FK_SLIDE(16, 2, 2) FK_SLIDE(16, 2, 4)
+        FK_SLIDE(16, 1, 2) FK_SLIDE(16, 1, 4) FK_SLIDE(32, 1, 2) FK_SLIDE(32, 1, 4) FK_SLIDE(8, 1, 4)
+#undef FK_SLIDE
+        return hipErrorInvalidValue;
+    }
     const int nt = P2 < 256 ? P2 : 256;
     int tt = 1;
     while (tt * 2 <= time_tile && tt < 16) tt *= 2;
