@@ -52,7 +52,8 @@ struct fe_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::mutex mu;
-    std::map<int, float2*> tw;              // log2P -> [exp(-2 pi i k / 2P), k < 2P | pass twiddles]
+    std::map<int, float2*> tw;              // log2P -> [exp(-2 pi i k / 2P), k < 2P | stage A | stage B tables]
+    std::map<int, std::pair<int, int>> tw_off;
     float2* Y = nullptr;
     size_t Y_rows_bytes = 0;
     // rotating pinned/device buffers for job descriptors (async uploads)
@@ -118,23 +119,25 @@ int resolve(const fe_filter* f, int idx) {
     return idx;
 }
 
-int get_twiddles(fe_engine* e, int log2P, const float2** out, const float2** out_pass) {
-    const int n = 2 << log2P;  // 2P entries for the real-FFT split, then the Stockham pass tables
+int get_twiddles(fe_engine* e, int log2P, fk::FftTables* out) {
     auto it = e->tw.find(log2P);
-    if (it != e->tw.end()) { *out = it->second; *out_pass = it->second + n; return FE_OK; }
-    const int np = fk::pass_twiddle_count(log2P);
-    std::vector<float2> host((size_t)n + (size_t)np);
-    for (int k = 0; k < n; ++k) {
-        const double a = -2.0 * M_PI * (double)k / (double)n;
-        host[(size_t)k] = float2{(float)std::cos(a), (float)std::sin(a)};
+    if (it == e->tw.end()) {
+        const int n = fk::fft_table_count(log2P);
+        if (n <= 0) return fail(FE_ERR_PARAM, "unsupported block size 2^%d", log2P);
+        std::vector<float2> host((size_t)n);
+        int off_a = 0, off_b = 0;
+        fk::fill_fft_tables(log2P, host.data(), &off_a, &off_b);
+        float2* dev = nullptr;
+        HIP_TRY(hipMalloc(&dev, sizeof(float2) * host.size()));
+        HIP_TRY(hipMemcpy(dev, host.data(), sizeof(float2) * host.size(), hipMemcpyHostToDevice));
+        e->tw[log2P] = dev;
+        e->tw_off[log2P] = std::make_pair(off_a, off_b);
+        it = e->tw.find(log2P);
     }
-    fk::fill_pass_twiddles(log2P, host.data() + n);
-    float2* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, sizeof(float2) * host.size()));
-    HIP_TRY(hipMemcpy(dev, host.data(), sizeof(float2) * host.size(), hipMemcpyHostToDevice));
-    e->tw[log2P] = dev;
-    *out = dev;
-    *out_pass = dev + n;
+    const std::pair<int, int> off = e->tw_off[log2P];
+    out->tw = it->second;
+    out->twa = it->second + off.first;
+    out->twb = it->second + off.second;
     return FE_OK;
 }
 
@@ -476,9 +479,8 @@ int fe_filter_commit(fe_filter* f) {
     }
     out_first[(size_t)f->nout] = (int)entries.size();
 
-    const float2* tw = nullptr;
-    const float2* ptw = nullptr;
-    int rc = get_twiddles(e, f->log2P, &tw, &ptw);
+    fk::FftTables tabs{};
+    int rc = get_twiddles(e, f->log2P, &tabs);
     if (rc) return rc;
     HIP_TRY(hipMalloc((void**)&f->out_first_dev, out_first.size() * sizeof(int)));
     HIP_TRY(hipMemcpy(f->out_first_dev, out_first.data(), out_first.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -500,14 +502,15 @@ int fe_filter_commit(fe_filter* f) {
         HIP_TRY(hipMalloc((void**)&f->H, per * f->ndata * sizeof(float2)));
         HIP_TRY(hipMalloc((void**)&f->mask_dev, masks.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(f->mask_dev, masks.data(), masks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(fk::launch_filter_transform(taps_dev, f->H, f->ndata, K, f->log2P, tw, ptw, e->stream));
+        HIP_TRY(fk::launch_filter_transform(taps_dev, f->H, f->ndata, K, f->log2P, tabs, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         HIP_TRY(hipFree(taps_dev));
     }
     f->dev.cin = f->ninp; f->dev.cout = f->nout; f->dev.P = P; f->dev.log2P = f->log2P; f->dev.K = K;
     f->dev.H = f->H; f->dev.mask = f->mask_dev; f->dev.paths = f->paths_dev; f->dev.out_first = f->out_first_dev;
-    f->dev.tw = tw;
-    f->dev.ptw = ptw;
+    f->dev.tw = tabs.tw;
+    f->dev.twa = tabs.twa;
+    f->dev.twb = tabs.twb;
     f->committed = true;
     return FE_OK;
 }

@@ -128,12 +128,49 @@ FK_HD int phys(int i) { return i + (i >> 4); }
 
 #if defined(__HIPCC__)
 
-// One Stockham pass.  src(i) yields element i of the pass input (LDS or
-// global), dst(i, v) consumes element i of the pass output.  When the input is
-// the LDS image that dst overwrites, SYNC_AFTER_READ separates the phases.
+// ---- synchronisation policies ------------------------------------------------
+struct WorkgroupSync {
+    static FK_D void sync() { __syncthreads(); }
+};
+// The lanes of ONE wavefront exchanging data through LDS: DS operations of a
+// wave execute in order, so all that is needed is that the compiler keeps the
+// program order and every lane's data have returned.
+struct WaveSync {
+    static FK_D void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+// Twiddles w[r] = W^r, r = 1..R-1, from the power-of-two rows of a pass table
+// (table[(r-1)*NS + k]): rows 1,2,4,8 are read (coalesced), the other powers are
+// products of at most three factors.  FULL: read every row (short periods, L1).
+template <int R, int NS, bool FULL>
+FK_D void load_twiddles(float2 (&w)[R], const float2* __restrict__ table, int k) {
+    if constexpr (FULL) {
+#pragma unroll
+        for (int r = 1; r < R; ++r) w[r] = table[(r - 1) * NS + k];
+    } else {
+#pragma unroll
+        for (int r = 1; r < R; r *= 2) w[r] = table[(r - 1) * NS + k];
+#pragma unroll
+        for (int r = 3; r < R; ++r) {
+            if ((r & (r - 1)) != 0) {
+                int top = 1;
+                while (top * 2 <= r) top *= 2;
+                w[r] = cmul(w[top], w[r - top]);
+            }
+        }
+    }
+}
+
+// One in-place Stockham pass over an N-point sequence held in a padded LDS image
+// (element i at s[phys(i)]), executed by NT threads.  Sync separates the read and
+// write phases (the caller synchronises after the pass).
 //   tw: this pass's table, tw[(r-1)*NS + k] = exp(-2*pi*i*k*r/(NS*R))
-template <int N, int NT, int R, int NS, bool INV, bool SYNC_AFTER_READ, class Src, class Dst>
-FK_D void stockham_pass(Src&& src, Dst&& dst, const float2* __restrict__ tw, int tid) {
+template <int N, int NT, int R, int NS, bool INV, class Sync>
+FK_D void stockham_pass(float2* s, const float2* __restrict__ tw, int tid) {
     constexpr int NB = N / R;                       // butterflies in this pass
     constexpr int CNT = (NB + NT - 1) / NT;         // per thread
     constexpr bool GUARD = (NB % NT) != 0;
@@ -143,73 +180,136 @@ FK_D void stockham_pass(Src&& src, Dst&& dst, const float2* __restrict__ tw, int
         const int j = tid + c * NT;
         if (!GUARD || j < NB) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[c][r] = src(j + r * NB);
+            for (int r = 0; r < R; ++r) v[c][r] = s[phys(j + r * NB)];
         }
     }
-    if constexpr (SYNC_AFTER_READ) __syncthreads();
+    Sync::sync();
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
         const int j = tid + c * NT;
         if (!GUARD || j < NB) {
             const int k = j & (NS - 1);
             if constexpr (NS > 1) {
-                float2 w[R];                                  // w[r] = exp(-2*pi*i*k*r/(NS*R))
-                if constexpr (NS <= kTableMaxPeriod) {
-#pragma unroll
-                    for (int r = 1; r < R; ++r) w[r] = tw[(r - 1) * NS + k];
-                } else {
-#pragma unroll
-                    for (int r = 1; r < R; r *= 2) w[r] = tw[(r - 1) * NS + k];
-#pragma unroll
-                    for (int r = 3; r < R; ++r) {
-                        if ((r & (r - 1)) != 0) {             // not a power of two: top bit * remainder
-                            int top = 1;
-                            while (top * 2 <= r) top *= 2;
-                            w[r] = cmul(w[top], w[r - top]);
-                        }
-                    }
-                }
+                float2 w[R];
+                load_twiddles<R, NS, (NS <= kTableMaxPeriod)>(w, tw, k);
 #pragma unroll
                 for (int r = 1; r < R; ++r) v[c][r] = INV ? cmulc(v[c][r], w[r]) : cmul(v[c][r], w[r]);
             }
             dft<R, INV>(v[c]);
             const int j0 = (j - k) * R + k;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst(j0 + r * NS, v[c][r]);
+            for (int r = 0; r < R; ++r) s[phys(j0 + r * NS)] = v[c][r];
         }
     }
 }
 
-// All passes of an N-point transform.  The first pass reads through `first`
-// (any source), middle passes run in place in the padded LDS image `s`, the
-// last pass writes through `last` (any sink).  FIRST_IN_PLACE / LAST_IN_PLACE say
-// that `first` reads / `last` writes the same LDS image (a barrier then splits
-// the pass).  Callers put a __syncthreads() after this if `last` wrote LDS that
-// other threads will read.
-template <int LOG2N, bool INV, bool FIRST_IN_PLACE, bool LAST_IN_PLACE, class First, class Last>
-FK_D void fft_passes(float2* s, const float2* __restrict__ ptw, int tid, First&& first, Last&& last) {
+// N-point FFT in place in one padded LDS image by NT threads: natural order in,
+// natural order out.  Ends with the data written and synchronised.
+template <int LOG2N, int NT, bool INV, class Sync>
+FK_D void lds_fft(float2* s, const float2* __restrict__ ptw, int tid) {
     constexpr int N = 1 << LOG2N;
-    constexpr int NT = threads_for(N);
     constexpr Plan pl = make_plan(LOG2N);
-    auto lds_src = [&](int i) { return s[phys(i)]; };
-    auto lds_dst = [&](int i, float2 v) { s[phys(i)] = v; };
     static_assert(pl.n >= 2 && pl.n <= 4, "plan");
     constexpr int R0 = pl.r[0], R1 = pl.r[1], R2 = pl.r[2], R3 = pl.r[3];
-    stockham_pass<N, NT, R0, 1, INV, FIRST_IN_PLACE>(first, lds_dst, ptw, tid);
-    __syncthreads();
-    if constexpr (pl.n == 2) {
-        stockham_pass<N, NT, R1, R0, INV, LAST_IN_PLACE>(lds_src, last, ptw + pl.off[1], tid);
-    } else if constexpr (pl.n == 3) {
-        stockham_pass<N, NT, R1, R0, INV, true>(lds_src, lds_dst, ptw + pl.off[1], tid);
-        __syncthreads();
-        stockham_pass<N, NT, R2, R0 * R1, INV, LAST_IN_PLACE>(lds_src, last, ptw + pl.off[2], tid);
-    } else {
-        stockham_pass<N, NT, R1, R0, INV, true>(lds_src, lds_dst, ptw + pl.off[1], tid);
-        __syncthreads();
-        stockham_pass<N, NT, R2, R0 * R1, INV, true>(lds_src, lds_dst, ptw + pl.off[2], tid);
-        __syncthreads();
-        stockham_pass<N, NT, R3, R0 * R1 * R2, INV, LAST_IN_PLACE>(lds_src, last, ptw + pl.off[3], tid);
+    stockham_pass<N, NT, R0, 1, INV, Sync>(s, ptw, tid);
+    Sync::sync();
+    stockham_pass<N, NT, R1, R0, INV, Sync>(s, ptw + pl.off[1], tid);
+    Sync::sync();
+    if constexpr (pl.n >= 3) {
+        stockham_pass<N, NT, R2, R0 * R1, INV, Sync>(s, ptw + pl.off[2], tid);
+        Sync::sync();
     }
+    if constexpr (pl.n >= 4) {
+        stockham_pass<N, NT, R3, R0 * R1 * R2, INV, Sync>(s, ptw + pl.off[3], tid);
+        Sync::sync();
+    }
+}
+
+// ---- wave-autonomous P-point FFT ----------------------------------------------
+// P = N1 * N2 with N1 = wavefronts in the workgroup and N2 = 1024 (16 points per
+// lane); P <= 1024 is a single wavefront.  Stage A is one radix-N1 decimation
+// step across the workgroup, done in registers straight from the source:
+//     A[k1][n2] = W_P^(n2*k1) * sum_n1 z[n1*N2 + n2] * W_N1^(n1*k1)
+// written to LDS row k1.  After ONE workgroup barrier wavefront k1 transforms its
+// own row (N2 points, wave-level synchronisation only):
+//     Z[k1 + N1*k2] = sum_n2 A[k1][n2] * W_N2^(n2*k2)
+// so the waves of a CU drift apart and hide each other's latencies instead of
+// meeting at eight barriers per transform.
+template <int LOG2P>
+struct WaveGeom {
+    static constexpr int P = 1 << LOG2P;
+    static constexpr int NT = threads_for(P);
+    static constexpr int N1 = (P >= 1024) ? P / 1024 : 1;      // == waves per workgroup
+    static constexpr int N2 = P / N1;
+    static constexpr int LOG2N2 = LOG2P - (N1 == 8 ? 3 : N1 == 4 ? 2 : N1 == 2 ? 1 : 0);
+    // Row stride: the padded row plus 32/N1 so that a transposed read (lanes along
+    // k = k1 + N1*k2) touches 32 distinct 8-byte banks.
+    static constexpr int RS = lds_elems(N2) + (N1 > 1 ? 32 / N1 : 0);
+    static constexpr int LDS_ELEMS = N1 * RS;
+    static constexpr int COLS = (N2 + NT - 1) / NT;             // stage-A columns per thread
+    static_assert(NT == 64 * N1 || N1 == 1, "one wavefront per row");
+    // element Z[k] after stage B
+    static FK_HD int at(int k) { return (k % N1) * RS + phys(k / N1); }
+    // twiddle buffers (host fills them: kernels.hip fill_fft_tables)
+    static constexpr int TWA = (N1 > 1) ? 3 * N2 : 0;           // stage A rows k1 = 1, 2, 4
+    static constexpr int TWB = make_plan(LOG2N2).total;         // stage B pass tables
+};
+
+// Stage A for one column n2 whose N1 inputs z[n1*N2 + n2] are in v.
+//   twa[(row)*N2 + n2], row 0,1,2 <-> k1 = 1,2,4: exp(-2*pi*i*n2*k1/P)
+template <int LOG2P, bool INV>
+FK_D void stage_a_column(float2* s, const float2* __restrict__ twa, int n2, float2 (&v)[WaveGeom<LOG2P>::N1]) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int N1 = G::N1, N2 = G::N2;
+    if constexpr (N1 > 1) {
+        dft<N1, INV>(v);
+        float2 w[N1];
+#pragma unroll
+        for (int r = 1, row = 0; r < N1; r *= 2, ++row) w[r] = twa[row * N2 + n2];
+#pragma unroll
+        for (int r = 3; r < N1; ++r) {
+            if ((r & (r - 1)) != 0) {
+                int top = 1;
+                while (top * 2 <= r) top *= 2;
+                w[r] = cmul(w[top], w[r - top]);
+            }
+        }
+#pragma unroll
+        for (int r = 1; r < N1; ++r) v[r] = INV ? cmulc(v[r], w[r]) : cmul(v[r], w[r]);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) s[k1 * G::RS + phys(n2)] = v[k1];
+}
+
+// Stage A for the columns this thread owns (n2 = tid + c*NT).  src(i) -> z[i].
+// All loads are issued before the first butterfly.
+template <int LOG2P, bool INV, class Src>
+FK_D void stage_a(float2* s, const float2* __restrict__ twa, int tid, Src&& src) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
+    constexpr bool GUARD = (N2 % NT) != 0;
+    float2 v[COLS][N1];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        const int n2 = tid + c * NT;
+        if (!GUARD || n2 < N2) {
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) v[c][n1] = src(n1 * N2 + n2);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        const int n2 = tid + c * NT;
+        if (!GUARD || n2 < N2) stage_a_column<LOG2P, INV>(s, twa, n2, v[c]);
+    }
+}
+
+// Stage B: every wavefront transforms its own row.
+template <int LOG2P, bool INV>
+FK_D void stage_b(float2* s, const float2* __restrict__ twb, int tid) {
+    using G = WaveGeom<LOG2P>;
+    float2* row = s + (tid >> 6) * G::RS;
+    lds_fft<G::LOG2N2, 64, INV, WaveSync>(row, twb, tid & 63);
 }
 
 #endif  // __HIPCC__

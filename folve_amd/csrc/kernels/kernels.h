@@ -44,8 +44,9 @@ struct FilterDev {
     const uint32_t* mask;   // [ndata][4] populated-partition bitmap (K <= 128)
     const PathEntry* paths; // grouped by output channel
     const int* out_first;   // [cout + 1] prefix into paths
-    const float2* tw;       // exp(-2*pi*i*k/(2P)), k in [0, P/2]   (real-FFT split / fold)
-    const float2* ptw;      // per-pass Stockham twiddles of the P-point FFT (fft_core.hpp: Plan::off)
+    const float2* tw;       // exp(-2*pi*i*k/(2P)), k in [0, 2P)   (real-FFT split / fold)
+    const float2* twa;      // stage A rows k1 = 1,2,4: exp(-2*pi*i*n2*k1/P)  (fft_core.hpp WaveGeom)
+    const float2* twb;      // stage B (per-wavefront N2-point FFT) pass tables
 };
 
 // K1: PCM -> spectra.  grid (max blocks, cin, jobs)
@@ -56,11 +57,12 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
 // K3: spectra -> PCM (last P of each 2P window) + peaks.  grid (max blocks, cout, jobs)
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
                           hipStream_t st);
+struct FftTables { const float2* tw; const float2* twa; const float2* twb; };
 // K0: time-domain taps [ndata][K*P] -> H [ndata][K][P] (scaled by 1/(2P)).
-hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const float2* tw,
-                                   const float2* ptw, hipStream_t st);
-// Host-side description of the pass-twiddle buffer for a P-point FFT.
-int pass_twiddle_count(int log2P);
-void fill_pass_twiddles(int log2P, float2* dst);   // dst[pass_twiddle_count(log2P)]
+hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const FftTables& t,
+                                   hipStream_t st);
+// Host-side description of the twiddle buffer of a P-point engine.
+int fft_table_count(int log2P);
+void fill_fft_tables(int log2P, float2* dst, int* off_twa, int* off_twb);   // dst[fft_table_count(log2P)]
 
 }  // namespace fk

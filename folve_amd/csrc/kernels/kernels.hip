@@ -36,24 +36,47 @@ __device__ __forceinline__ int ring_slot(int slot0, int rel, int ring) {
     return s < 0 ? s + ring : s;
 }
 
-// After the forward passes left Z (P-point FFT of z[m] = x[2m] + i x[2m+1]) in
-// the LDS image, form the 2P-point real spectrum and store it as a packed row.
+// After stage B left Z (P-point FFT of z[m] = x[2m] + i x[2m+1]) in the LDS rows,
+// form the 2P-point real spectrum and store it as a packed row.  The e^(-i*pi*k/P)
+// factors are requested before the barrier that precedes this call (wsp).
 template <int LOG2P>
-__device__ __forceinline__ void split_and_store(const float2* s, const float2* __restrict__ tw, int tid,
+struct SplitGeom {
+    static constexpr int P = 1 << LOG2P;
+    static constexpr int NT = WaveGeom<LOG2P>::NT;
+    static constexpr int CNT = (P / 2 + NT - 1) / NT;
+};
+
+template <int LOG2P>
+__device__ __forceinline__ void split_prefetch(float2 (&wsp)[SplitGeom<LOG2P>::CNT], const float2* __restrict__ tw,
+                                               int tid) {
+    using S = SplitGeom<LOG2P>;
+#pragma unroll
+    for (int c = 0; c < S::CNT; ++c) {
+        const int k = tid + c * S::NT;
+        wsp[c] = (k < S::P / 2) ? tw[k] : float2{1.f, 0.f};
+    }
+}
+
+template <int LOG2P>
+__device__ __forceinline__ void split_and_store(const float2* s, const float2 (&wsp)[SplitGeom<LOG2P>::CNT], int tid,
                                                 float2* __restrict__ row, float scale) {
-    constexpr int P = 1 << LOG2P;
-    constexpr int NT = threads_for(P);
-    for (int k = tid; k < P / 2; k += NT) {
+    using S = SplitGeom<LOG2P>;
+    using G = WaveGeom<LOG2P>;
+    constexpr int P = S::P;
+#pragma unroll
+    for (int c = 0; c < S::CNT; ++c) {
+        const int k = tid + c * S::NT;
+        if (k >= P / 2) continue;
         if (k == 0) {
-            const float2 z0 = s[phys(0)];
+            const float2 z0 = s[G::at(0)];
             row[0] = float2{(z0.x + z0.y) * scale, (z0.x - z0.y) * scale};   // (DC, Nyquist)
-            const float2 zh = s[phys(P / 2)];
+            const float2 zh = s[G::at(P / 2)];
             row[P / 2] = float2{zh.x * scale, -zh.y * scale};
         } else {
-            const float2 a = s[phys(k)], b = s[phys(P - k)];
+            const float2 a = s[G::at(k)], b = s[G::at(P - k)];
             const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
             const float2 o = float2{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
-            const float2 t = cmul(o, tw[k]);
+            const float2 t = cmul(o, wsp[c]);
             row[k] = float2{(e.x + t.x) * scale, (e.y + t.y) * scale};
             row[P - k] = float2{(e.x - t.x) * scale, -(e.y - t.y) * scale};
         }
@@ -64,10 +87,11 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2* _
 // K1: forward.  grid (max blocks per stream, input channels, streams)
 // ---------------------------------------------------------------------------
 template <int LOG2P>
-__global__ __launch_bounds__(threads_for(1 << LOG2P)) void forward_kernel(const StreamJob* __restrict__ jobs,
-                                                                          FilterDev f) {
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const StreamJob* __restrict__ jobs,
+                                                                      FilterDev f) {
+    using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
-    __shared__ float2 s[lds_elems(P)];
+    __shared__ float2 s[G::LDS_ELEMS];
     const StreamJob job = jobs[blockIdx.z];
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
@@ -101,43 +125,59 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void forward_kernel(const 
         }
         return v;
     };
-    auto lds_dst = [&](int i, float2 v) { s[phys(i)] = v; };
-    fft_passes<LOG2P, false, false, true>(s, f.ptw, tid, load, lds_dst);
+    stage_a<LOG2P, false>(s, f.twa, tid, load);
+    __syncthreads();
+    stage_b<LOG2P, false>(s, f.twb, tid);
+    float2 wsp[SplitGeom<LOG2P>::CNT];
+    split_prefetch<LOG2P>(wsp, f.tw, tid);
     __syncthreads();
     const int slot = ring_slot(job.slot0, b, job.ring);
     float2* row = job.fdl + ((size_t)c * job.ring + slot) * P;
-    split_and_store<LOG2P>(s, f.tw, tid, row, 1.0f);
+    split_and_store<LOG2P>(s, wsp, tid, row, 1.0f);
 }
 
 // ---------------------------------------------------------------------------
 // K0: filter partitions -> spectra.  grid (K, data paths)
 // ---------------------------------------------------------------------------
 template <int LOG2P>
-__global__ __launch_bounds__(threads_for(1 << LOG2P)) void filter_kernel(const float* __restrict__ taps,
-                                                                         float2* __restrict__ H, int K,
-                                                                         const float2* __restrict__ tw,
-                                                                         const float2* __restrict__ ptw) {
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void filter_kernel(const float* __restrict__ taps,
+                                                                     float2* __restrict__ H, int K,
+                                                                     const float2* __restrict__ tw,
+                                                                     const float2* __restrict__ twa,
+                                                                     const float2* __restrict__ twb) {
+    using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
-    __shared__ float2 s[lds_elems(P)];
+    __shared__ float2 s[G::LDS_ELEMS];
     const int j = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const float2* __restrict__ part = reinterpret_cast<const float2*>(taps + ((size_t)d * K + j) * P);
     auto load = [&](int m) -> float2 { return (m < P / 2) ? part[m] : float2{0.0f, 0.0f}; };   // [h_j | 0]
-    auto lds_dst = [&](int i, float2 v) { s[phys(i)] = v; };
-    fft_passes<LOG2P, false, false, true>(s, ptw, tid, load, lds_dst);
+    stage_a<LOG2P, false>(s, twa, tid, load);
     __syncthreads();
-    split_and_store<LOG2P>(s, tw, tid, H + ((size_t)d * K + j) * P, 0.5f / (float)P);
+    stage_b<LOG2P, false>(s, twb, tid);
+    float2 wsp[SplitGeom<LOG2P>::CNT];
+    split_prefetch<LOG2P>(wsp, tw, tid);
+    __syncthreads();
+    split_and_store<LOG2P>(s, wsp, tid, H + ((size_t)d * K + j) * P, 0.5f / (float)P);
 }
 
 // ---------------------------------------------------------------------------
 // K3: inverse.  grid (max blocks per stream, output channels, streams)
+//
+// The Hermitian fold Z[k] = E[k] + i O[k], E = Y[k] + conj Y[P-k],
+// O = (Y[k] - conj Y[P-k]) e^(+i*pi*k/P) pairs k with P-k.  A thread owns stage-A
+// columns in pairs (p, N2-p) — slot 0 owns the self-paired columns 0 and N2/2 —
+// so both members of every pair sit in its own registers: no LDS pass, no
+// second read of Y.
 // ---------------------------------------------------------------------------
 template <int LOG2P>
-__global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const StreamJob* __restrict__ jobs,
-                                                                          FilterDev f,
-                                                                          const float2* __restrict__ Y) {
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const StreamJob* __restrict__ jobs,
+                                                                      FilterDev f,
+                                                                      const float2* __restrict__ Y) {
+    using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
-    constexpr int NT = threads_for(P);
-    __shared__ float2 s[lds_elems(P)];
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
+    constexpr int SLOTS = (N2 / 2 + NT - 1) / NT;            // column pairs per thread
+    __shared__ float2 s[G::LDS_ELEMS];
     const StreamJob job = jobs[blockIdx.z];
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
@@ -147,53 +187,98 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const 
     const float2* __restrict__ y = Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P;
     const float2* __restrict__ tw = f.tw;
 
-    // Hermitian fold: Z[k] = E[k] + i O[k], E = Y[k] + conj Y[P-k], O = (Y[k] - conj Y[P-k]) W^-k
-    for (int k = tid; k < P / 2; k += NT) {
-        if (k == 0) {
-            const float2 y0 = y[0];                       // (DC, Nyquist)
-            s[phys(0)] = float2{y0.x + y0.y, y0.x - y0.y};
-            const float2 yh = y[P / 2];
-            s[phys(P / 2)] = float2{2.0f * yh.x, -2.0f * yh.y};
-        } else {
-            const float2 a = y[k], bb = y[P - k];
-            const float2 e = float2{a.x + bb.x, a.y - bb.y};
-            const float2 dd = float2{a.x - bb.x, a.y + bb.y};
-            const float2 oo = cmulc(dd, tw[k]);           // * exp(+i*pi*k/P)
-            s[phys(k)] = float2{e.x - oo.y, e.y + oo.x};
-            s[phys(P - k)] = float2{e.x + oo.y, -e.y + oo.x};
+    // ---- loads: the two columns of each slot, and the twiddles of the first ----
+    float2 ya[SLOTS][N1], yb[SLOTS][N1], wa[SLOTS][N1];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int p = tid + q * NT;
+        if (p < N2 / 2) {
+            const int ca = p, cb = (p == 0) ? N2 / 2 : N2 - p;
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) {
+                ya[q][n1] = y[n1 * N2 + ca];
+                yb[q][n1] = y[n1 * N2 + cb];
+                wa[q][n1] = tw[n1 * N2 + ca];                 // e^(-i*pi*k/P), k = n1*N2 + ca
+            }
+        }
+    }
+    // ---- fold in registers, stage A, rows to LDS ----
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int p = tid + q * NT;
+        if (p < N2 / 2) {
+            float2 za[N1], zb[N1];
+            if (p != 0) {
+                // k = n1*N2 + p  <->  P - k = (N1-1-n1)*N2 + (N2 - p);  e^(-i*pi*(P-k)/P) = -conj(e^(-i*pi*k/P))
+#pragma unroll
+                for (int n1 = 0; n1 < N1; ++n1) {
+                    const float2 a = ya[q][n1], bb = yb[q][N1 - 1 - n1];
+                    const float2 e = float2{a.x + bb.x, a.y - bb.y};
+                    const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                    const float2 oo = cmulc(dd, wa[q][n1]);
+                    za[n1] = float2{e.x - oo.y, e.y + oo.x};
+                    zb[N1 - 1 - n1] = float2{e.x + oo.y, -e.y + oo.x};
+                }
+            } else {
+                // column 0: k = n1*N2 <-> (N1-n1)*N2 (k = 0 is the packed (DC, Nyquist) bin);
+                // column N2/2: k = n1*N2 + N2/2 <-> (N1-1-n1)*N2 + N2/2.  Both pair inside the column.
+#pragma unroll
+                for (int n1 = 0; n1 < N1; ++n1) {
+                    if (n1 == 0) {
+                        const float2 y0 = ya[q][0];
+                        za[0] = float2{y0.x + y0.y, y0.x - y0.y};
+                    } else {
+                        const float2 a = ya[q][n1], bb = ya[q][N1 - n1];
+                        const float2 e = float2{a.x + bb.x, a.y - bb.y};
+                        const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                        const float2 oo = cmulc(dd, wa[q][n1]);
+                        za[n1] = float2{e.x - oo.y, e.y + oo.x};
+                    }
+                    const float2 a = yb[q][n1], bb = yb[q][N1 - 1 - n1];
+                    const float2 e = float2{a.x + bb.x, a.y - bb.y};
+                    const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                    const float2 oo = cmulc(dd, tw[n1 * N2 + N2 / 2]);
+                    zb[n1] = float2{e.x - oo.y, e.y + oo.x};
+                }
+            }
+            const int ca = p, cb = (p == 0) ? N2 / 2 : N2 - p;
+            stage_a_column<LOG2P, true>(s, f.twa, ca, za);
+            stage_a_column<LOG2P, true>(s, f.twa, cb, zb);
         }
     }
     __syncthreads();
+    stage_b<LOG2P, true>(s, f.twb, tid);
+    __syncthreads();
 
+    // ---- transposed read: consecutive lanes take consecutive output frames ----
     float* __restrict__ out = job.out;
     const bool wide1 = (cout == 1) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
     const long long fb = (long long)b * P;
     float pk_s = 0.0f, pk_a = 0.0f;
-    auto lds_src = [&](int i) { return s[phys(i)]; };
-    // z[q] = (y[2q], y[2q+1]); overlap-save keeps samples P..2P-1 (q >= P/2)
-    auto store = [&](int q, float2 z) {
-        if (q >= P / 2) {
-            const long long fr = fb + 2 * q - P;
-            if (wide1 && fr + 1 < job.nframes) {             // mono: the pair is contiguous
-                *reinterpret_cast<float2*>(out + fr) = z;
-                pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
-                pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
-                return;
-            }
-            if (fr < job.nframes) {
-                out[fr * cout + o] = z.x;
-                pk_s = fmaxf(pk_s, z.x);
-                pk_a = fmaxf(pk_a, fabsf(z.x));
-            }
-            if (fr + 1 < job.nframes) {
-                out[(fr + 1) * cout + o] = z.y;
-                pk_s = fmaxf(pk_s, z.y);
-                pk_a = fmaxf(pk_a, fabsf(z.y));
-            }
+    constexpr int OUTS = (P / 2 + NT - 1) / NT;
+#pragma unroll
+    for (int c = 0; c < OUTS; ++c) {
+        const int q = P / 2 + tid + c * NT;                  // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
+        if (q >= P) continue;
+        const float2 z = s[G::at(q)];
+        const long long fr = fb + 2 * q - P;
+        if (wide1 && fr + 1 < job.nframes) {                 // mono: the pair is contiguous
+            *reinterpret_cast<float2*>(out + fr) = z;
+            pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
+            pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
+            continue;
         }
-    };
-    fft_passes<LOG2P, true, true, false>(s, f.ptw, tid, lds_src, store);
-
+        if (fr < job.nframes) {
+            out[fr * cout + o] = z.x;
+            pk_s = fmaxf(pk_s, z.x);
+            pk_a = fmaxf(pk_a, fabsf(z.x));
+        }
+        if (fr + 1 < job.nframes) {
+            out[(fr + 1) * cout + o] = z.y;
+            pk_s = fmaxf(pk_s, z.y);
+            pk_a = fmaxf(pk_a, fabsf(z.y));
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         pk_s = fmaxf(pk_s, __shfl_xor(pk_s, off, 64));
@@ -205,7 +290,6 @@ __global__ __launch_bounds__(threads_for(1 << LOG2P)) void inverse_kernel(const 
         atomicMax(job.peaks + 1, __float_as_uint(pk_a));
     }
 }
-
 
 // Packed bin 0 = (DC, Nyquist): two real products, not a complex one.  Done by
 // the first TT threads of the workgroup that owns bin 0, one output block each.
@@ -402,7 +486,7 @@ hipError_t dispatch_log2p(int log2P, A&&... a) {
 template <int L>
 struct FwdLaunch {
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, hipStream_t st) {
-        dim3 grid(max_blocks, f.cin, njobs), block(threads_for(1 << L));
+        dim3 grid(max_blocks, f.cin, njobs), block(WaveGeom<L>::NT);
         hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f);
         return hipGetLastError();
     }
@@ -411,17 +495,16 @@ template <int L>
 struct InvLaunch {
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
                           hipStream_t st) {
-        dim3 grid(max_blocks, f.cout, njobs), block(threads_for(1 << L));
+        dim3 grid(max_blocks, f.cout, njobs), block(WaveGeom<L>::NT);
         hipLaunchKernelGGL(inverse_kernel<L>, grid, block, 0, st, jobs, f, Y);
         return hipGetLastError();
     }
 };
 template <int L>
 struct FilterLaunch {
-    static hipError_t run(const float* taps, float2* H, int ndata, int K, const float2* tw, const float2* ptw,
-                          hipStream_t st) {
-        dim3 grid(K, ndata), block(threads_for(1 << L));
-        hipLaunchKernelGGL(filter_kernel<L>, grid, block, 0, st, taps, H, K, tw, ptw);
+    static hipError_t run(const float* taps, float2* H, int ndata, int K, const FftTables& t, hipStream_t st) {
+        dim3 grid(K, ndata), block(WaveGeom<L>::NT);
+        hipLaunchKernelGGL(filter_kernel<L>, grid, block, 0, st, taps, H, K, t.tw, t.twa, t.twb);
         return hipGetLastError();
     }
 };
@@ -437,21 +520,55 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
     return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, st);
 }
 
-hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const float2* tw,
-                                   const float2* ptw, hipStream_t st) {
-    return dispatch_log2p<FilterLaunch>(log2P, taps, H, ndata, K, tw, ptw, st);
+hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const FftTables& t,
+                                   hipStream_t st) {
+    return dispatch_log2p<FilterLaunch>(log2P, taps, H, ndata, K, t, st);
 }
 
-int pass_twiddle_count(int log2P) { return make_plan(log2P).total; }
+// ---- twiddle buffer of a P-point engine: [ tw2P (2P) | stage A rows (3*N2) | stage B pass tables ] ----
+template <int L>
+struct TableLayout {
+    static hipError_t run(int* n_tw, int* n_twa, int* n_twb, int* n2, int* log2n2) {
+        *n_tw = 2 << L;
+        *n_twa = WaveGeom<L>::TWA;
+        *n_twb = WaveGeom<L>::TWB;
+        *n2 = WaveGeom<L>::N2;
+        *log2n2 = WaveGeom<L>::LOG2N2;
+        return hipSuccess;
+    }
+};
 
-void fill_pass_twiddles(int log2P, float2* dst) {
-    const Plan pl = make_plan(log2P);
+int fft_table_count(int log2P) {
+    int a, b, c, n2, l2;
+    if (dispatch_log2p<TableLayout>(log2P, &a, &b, &c, &n2, &l2) != hipSuccess) return 0;
+    return a + b + c;
+}
+
+void fill_fft_tables(int log2P, float2* dst, int* off_twa, int* off_twb) {
+    int n_tw, n_twa, n_twb, N2, log2n2;
+    (void)dispatch_log2p<TableLayout>(log2P, &n_tw, &n_twa, &n_twb, &N2, &log2n2);
+    const double P = (double)(1 << log2P);
+    for (int k = 0; k < n_tw; ++k) {
+        const double a = -M_PI * (double)k / P;                       // exp(-2*pi*i*k/(2P))
+        dst[k] = float2{(float)cos(a), (float)sin(a)};
+    }
+    *off_twa = n_tw;
+    *off_twb = n_tw + n_twa;
+    if (n_twa) {
+        for (int row = 0, k1 = 1; row < 3; ++row, k1 *= 2)
+            for (int n2 = 0; n2 < N2; ++n2) {
+                const double a = -2.0 * M_PI * (double)n2 * (double)k1 / P;
+                dst[n_tw + row * N2 + n2] = float2{(float)cos(a), (float)sin(a)};
+            }
+    }
+    const Plan pl = make_plan(log2n2);
+    float2* tb = dst + n_tw + n_twa;
     for (int p = 1; p < pl.n; ++p) {
         const int R = pl.r[p], NS = pl.ns[p];
         for (int r = 1; r < R; ++r)
             for (int k = 0; k < NS; ++k) {
                 const double a = -2.0 * M_PI * (double)k * (double)r / ((double)NS * (double)R);
-                dst[pl.off[p] + (r - 1) * NS + k] = float2{(float)cos(a), (float)sin(a)};
+                tb[pl.off[p] + (r - 1) * NS + k] = float2{(float)cos(a), (float)sin(a)};
             }
     }
 }

@@ -109,3 +109,45 @@ if __name__ == "__main__":
         ref = np.convolve(x, h)[: nb * P]
         assert np.allclose(y, ref), (P, np.abs(y - ref).max())
         print("P=%d ok plan=%s" % (P, plan(int(np.log2(P)))))
+
+
+# ---------------------------------------------------------------------------
+# Model of the wave-autonomous decomposition used by kernels.hip (v2):
+#   N = N1 * N2, N1 = wavefronts per workgroup, N2 = 1024 (or N when N < 1024)
+#   stage A: A[k1][n2] = DFT_N1 over n1 of z[n1*N2 + n2], times W_N^(n2*k1)
+#   stage B: wave k1: Z[k1 + N1*k2] = DFT_N2 over n2 of A[k1][n2]   (Stockham, in its LDS row)
+# ---------------------------------------------------------------------------
+def two_level(q, twoP):
+    """exp(-2*pi*i*q/twoP) as coarse[q>>5] * fine[q&31], like the LDS tables."""
+    q = np.asarray(q) % twoP
+    coarse = np.exp(-2j * np.pi * (q >> 5) * 32 / twoP)
+    fine = np.exp(-2j * np.pi * (q & 31) / twoP)
+    return coarse * fine
+
+
+def wave_fft(z, inverse=False):
+    n = len(z)
+    n1 = max(1, n // 1024)
+    n2 = n // n1
+    sign = 1.0 if inverse else -1.0
+    rows = np.empty((n1, n2), np.complex128)
+    col = np.arange(n2)
+    x = z.reshape(n1, n2)                       # x[n1][n2] = z[n1*N2 + n2]
+    W = np.exp(sign * 2j * np.pi * np.outer(np.arange(n1), np.arange(n1)) / n1)
+    a = W @ x                                   # a[k1][n2]
+    for k1 in range(n1):
+        tw = two_level(col * k1 * 2, 2 * n)     # W_N^(n2*k1) as a 2N-th root index
+        rows[k1] = a[k1] * (np.conj(tw) if inverse else tw)
+    out = np.empty(n, np.complex128)
+    for k1 in range(n1):
+        out[k1::n1] = stockham(rows[k1], inverse)   # Z[k1 + N1*k2]
+    return out
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    for P in (64, 256, 1024, 2048, 4096, 8192):
+        z = rng.standard_normal(P) + 1j * rng.standard_normal(P)
+        assert np.allclose(wave_fft(z), np.fft.fft(z))
+        assert np.allclose(wave_fft(z, True), np.fft.ifft(z) * P)
+    print("wave-autonomous decomposition ok")
