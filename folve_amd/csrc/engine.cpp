@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -54,8 +55,18 @@ struct fe_engine {
     std::mutex mu;
     std::map<int, float2*> tw;              // log2P -> [exp(-2 pi i k / 2P), k < 2P | stage A | stage B tables]
     std::map<int, std::pair<int, int>> tw_off;
-    float2* Y = nullptr;
-    size_t Y_rows_bytes = 0;
+    // Lanes: lane 0 is the engine's stream; lane 1 is a second HIP stream that a large
+    // batch forks half of its streams onto, so that one half's bandwidth-bound MAC runs
+    // beside the other half's latency-bound FFTs (fork/join with events per batch call).
+    struct Lane {
+        hipStream_t st = nullptr;
+        float2* Y = nullptr;
+        size_t Y_bytes = 0;
+    };
+    Lane lanes[2];
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int max_lanes = 2;
+    long long split_min_units = 512;     // block-channels below which a batch stays on one lane
     // rotating pinned/device buffers for job descriptors (async uploads)
     fk::StreamJob* jobs_host[kJobSlots] = {};
     fk::StreamJob* jobs_dev[kJobSlots] = {};
@@ -144,6 +155,7 @@ int get_twiddles(fe_engine* e, int log2P, fk::FftTables* out) {
 int ensure_bytes(fe_engine* e, void** ptr, size_t* have, size_t need) {
     if (*have >= need) return FE_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));   // nothing in flight may still use the old buffer
+    if (e->lanes[1].st) HIP_TRY(hipStreamSynchronize(e->lanes[1].st));
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     *have = 0;
@@ -161,11 +173,14 @@ struct Item {
 };
 
 // One launch round over streams that share a filter.
-int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any) {
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane_id = 0) {
+    fe_engine::Lane& lane = e->lanes[lane_id];
+    hipStream_t st = lane.st;
     const int P = f->P;
     std::vector<fk::StreamJob> jobs;
     jobs.reserve(items.size());
     int yunits = 0, max_blocks = 0;
+    bool walker_ok = true, any_partial = false;
     for (Item& it : items) {
         if (it.left <= 0) continue;
         fe_stream* s = it.s;
@@ -180,6 +195,8 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         j.tail_wr = s->tails + (size_t)(s->parity ^ 1) * tail_elems;
         j.peaks = s->peaks;
         j.nframes = take;
+        if (reinterpret_cast<uintptr_t>(it.in) & 15) walker_ok = false;
+        if (take % P) any_partial = true;
         j.nblocks = (int)((take + P - 1) / P);
         j.slot0 = s->slot0;
         j.yunit0 = yunits;
@@ -198,7 +215,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     *any = !jobs.empty();
     if (jobs.empty()) return FE_OK;
 
-    int rc = ensure_bytes(e, (void**)&e->Y, &e->Y_rows_bytes, (size_t)yunits * P * sizeof(float2));
+    int rc = ensure_bytes(e, (void**)&lane.Y, &lane.Y_bytes, (size_t)yunits * P * sizeof(float2));
     if (rc) return rc;
 
     // upload the descriptors through a rotating pinned buffer
@@ -219,21 +236,21 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         e->jobs_cap[slot] = cap;
     }
     memcpy(e->jobs_host[slot], jobs.data(), bytes);
-    HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipEventRecord(e->jobs_ev[slot], e->stream));
+    HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(e->jobs_ev[slot], st));
     e->jobs_ev_pending[slot] = true;
 
     const fk::StreamJob* dj = e->jobs_dev[slot];
     const int nj = (int)jobs.size();
     const bool prof = e->profiling;
-    if (prof) HIP_TRY(hipEventRecord(e->pev[0], e->stream));
-    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, e->stream));
-    if (prof) HIP_TRY(hipEventRecord(e->pev[1], e->stream));
-    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, e->Y, max_blocks, e->stream));
-    if (prof) HIP_TRY(hipEventRecord(e->pev[2], e->stream));
-    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, e->Y, e->stream));
+    if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
+    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, walker_ok, any_partial, st));
+    if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
+    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, lane.Y, max_blocks, st));
+    if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, lane.Y, st));
     if (prof) {
-        HIP_TRY(hipEventRecord(e->pev[3], e->stream));
+        HIP_TRY(hipEventRecord(e->pev[3], st));
         HIP_TRY(hipEventSynchronize(e->pev[3]));
         for (int k = 0; k < FE_K_COUNT; ++k) {
             float ms = 0.f;
@@ -261,8 +278,10 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         for (int k = 0; k < i; ++k)
             if (streams[k] == s) return fail(FE_ERR_PARAM, "stream listed twice in one batch");
         all[(size_t)i] = Item{s, in[i], out[i], nframes[i]};
-        in_floats += (size_t)nframes[i] * s->f->ninp;
-        out_floats += (size_t)nframes[i] * s->f->nout;
+        // staging offsets stay 16-byte aligned so that every stream takes the same kernel path
+        // as it would alone (a batch is bit-identical to its streams run one by one)
+        in_floats += ((size_t)nframes[i] * s->f->ninp + 3) & ~(size_t)3;
+        out_floats += ((size_t)nframes[i] * s->f->nout + 3) & ~(size_t)3;
     }
     if (!device_ptrs) {
         int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
@@ -275,8 +294,8 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             if (ni) HIP_TRY(hipMemcpyAsync(e->stage_in + io, in[i], ni * sizeof(float), hipMemcpyHostToDevice, e->stream));
             all[(size_t)i].in = e->stage_in + io;
             all[(size_t)i].out = e->stage_out + oo;
-            io += ni;
-            oo += no;
+            io += (ni + 3) & ~(size_t)3;
+            oo += (no + 3) & ~(size_t)3;
         }
     }
     // group by filter; each group runs launch rounds until its frames are consumed
@@ -288,18 +307,40 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         std::vector<int> idx;
         for (int k = i; k < n; ++k)
             if (!done[(size_t)k] && streams[k]->f == f) { group.push_back(all[(size_t)k]); idx.push_back(k); done[(size_t)k] = 1; }
-        bool any = true;
-        while (any) {
-            int rc = launch_round(e, f, group, &any);
-            if (rc) return rc;
+        long long units = 0;
+        for (const Item& it : group) units += (it.left + f->P - 1) / f->P * f->nout;
+        const bool split = !e->profiling && e->max_lanes > 1 && group.size() >= 2 && units >= e->split_min_units;
+        if (!split) {
+            bool any = true;
+            while (any) {
+                int rc = launch_round(e, f, group, &any, 0);
+                if (rc) return rc;
+            }
+            continue;
         }
+        if (!e->lanes[1].st) {
+            HIP_TRY(hipStreamCreateWithFlags(&e->lanes[1].st, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
+        }
+        std::vector<Item> half[2];
+        for (size_t k = 0; k < group.size(); ++k) half[k >= (group.size() + 1) / 2].push_back(group[k]);
+        HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->lanes[1].st, e->fork_ev, 0));
+        bool any0 = true, any1 = true;
+        while (any0 || any1) {
+            if (any0) { int rc = launch_round(e, f, half[0], &any0, 0); if (rc) return rc; }
+            if (any1) { int rc = launch_round(e, f, half[1], &any1, 1); if (rc) return rc; }
+        }
+        HIP_TRY(hipEventRecord(e->join_ev, e->lanes[1].st));
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
     }
     if (!device_ptrs) {
         size_t oo = 0;
         for (int i = 0; i < n; ++i) {
             const size_t no = (size_t)nframes[i] * streams[i]->f->nout;
             if (no) HIP_TRY(hipMemcpyAsync(out[i], e->stage_out + oo, no * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-            oo += no;
+            oo += (no + 3) & ~(size_t)3;
         }
     }
     if (!async) HIP_TRY(hipStreamSynchronize(e->stream));
@@ -345,6 +386,9 @@ int fe_engine_create(int device, void* hip_stream, fe_engine** out) {
         if (r != hipSuccess) { delete e; return fail(FE_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(r)); }
         e->own_stream = true;
     }
+    e->lanes[0].st = e->stream;
+    if (const char* env = getenv("FOLVE_AMD_LANES")) e->max_lanes = atoi(env) > 1 ? 2 : 1;
+    if (const char* env = getenv("FOLVE_AMD_SPLIT_MIN")) e->split_min_units = atoll(env);
     for (int i = 0; i < kJobSlots; ++i) {
         if (hipEventCreateWithFlags(&e->jobs_ev[i], hipEventDisableTiming) != hipSuccess) {
             delete e;
@@ -364,7 +408,11 @@ static void engine_release(fe_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->tw) (void)hipFree(kv.second);
-    if (e->Y) (void)hipFree(e->Y);
+    if (e->lanes[1].st) (void)hipStreamSynchronize(e->lanes[1].st);
+    for (auto& ln : e->lanes) if (ln.Y) (void)hipFree(ln.Y);
+    if (e->lanes[1].st) (void)hipStreamDestroy(e->lanes[1].st);
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    if (e->join_ev) (void)hipEventDestroy(e->join_ev);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     for (int i = 0; i < kJobSlots; ++i) {

@@ -50,7 +50,10 @@ struct FilterDev {
 };
 
 // K1: PCM -> spectra.  grid (max blocks, cin, jobs)
-hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, hipStream_t st);
+// walker_ok: every stream's PCM pointer is 16-byte aligned (lets mono / stereo streams take the
+// pair-walker kernel); any_partial: some stream ends in a short block.
+hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool walker_ok,
+                          bool any_partial, hipStream_t st);
 // K2: Y = sum over paths and partitions of X * H.  time_tile: outputs per thread (1,2,4,8,16)
 hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, float2* Y,
                       int time_tile, hipStream_t st);

@@ -69,8 +69,8 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
         if (k >= P / 2) continue;
         if (k == 0) {
             const float2 z0 = s[G::at(0)];
-            row[0] = float2{(z0.x + z0.y) * scale, (z0.x - z0.y) * scale};   // (DC, Nyquist)
             const float2 zh = s[G::at(P / 2)];
+            row[0] = float2{(z0.x + z0.y) * scale, (z0.x - z0.y) * scale};   // (DC, Nyquist)
             row[P / 2] = float2{zh.x * scale, -zh.y * scale};
         } else {
             const float2 a = s[G::at(k)], b = s[G::at(P - k)];
@@ -84,16 +84,19 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
 }
 
 // ---------------------------------------------------------------------------
-// K1: forward.  grid (max blocks per stream, input channels, streams)
+// K1, general form: one workgroup per (block, input channel).  grid (max blocks, input channels, streams)
+// Handles everything (any channel count, unaligned PCM, a short last block, P < 2048); the
+// pair-walker below takes the whole blocks of mono / stereo streams when it applies, and this
+// kernel is then launched with first_block = whole blocks, i.e. for a short last block only.
 // ---------------------------------------------------------------------------
 template <int LOG2P>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const StreamJob* __restrict__ jobs,
-                                                                      FilterDev f) {
+                                                                      FilterDev f, int skip_whole) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     __shared__ float2 s[G::LDS_ELEMS];
     const StreamJob job = jobs[blockIdx.z];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + (skip_whole ? (int)(job.nframes / P) : 0);   // the walker did the whole blocks
     if (b >= job.nblocks) return;
     const int c = blockIdx.y;
     const int tid = threadIdx.x;
@@ -134,6 +137,131 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
     const int slot = ring_slot(job.slot0, b, job.ring);
     float2* row = job.fdl + ((size_t)c * job.ring + slot) * P;
     split_and_store<LOG2P>(s, wsp, tid, row, 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// K1, fast form ("pair-walker"): whole blocks of mono / stereo PCM, P >= 2048.
+// grid (runs of `run` consecutive blocks, 1, streams)
+//
+// One workgroup owns the stream's channel pair and walks `run` consecutive blocks.
+// A block's interleaved PCM is loaded ONCE, as raw quads (L[2m], R[2m], L[2m+1],
+// R[2m+1]) — plain 16-byte loads — and feeds both channels' FFTs; the quads of block
+// n stay in registers as the x(n-1) half of block n+1's overlap-save window; the
+// loads of block n+1 are issued as soon as the second channel's stage A has consumed
+// the registers, so they fly during its stage B, split and stores.  Every PCM byte is
+// requested once (the general kernel asks for each byte four times: two windows x
+// two channels, and concurrent workgroups do not share through L2).
+// ---------------------------------------------------------------------------
+template <int CIN> struct PcmQuad;
+template <> struct PcmQuad<1> { using type = float2; };     // (x[2m], x[2m+1])
+template <> struct PcmQuad<2> { using type = float4; };     // (L[2m], R[2m], L[2m+1], R[2m+1])
+__device__ __forceinline__ float2 quad_channel(const float2& q, int) { return q; }
+__device__ __forceinline__ float2 quad_channel(const float4& q, int ch) {
+    return ch == 0 ? float2{q.x, q.z} : float2{q.y, q.w};
+}
+__device__ __forceinline__ void quad_from_tails(float2& q, const float2& t0, const float2&) { q = t0; }
+__device__ __forceinline__ void quad_from_tails(float4& q, const float2& t0, const float2& t1) {
+    q = float4{t0.x, t1.x, t0.y, t1.y};
+}
+
+template <int LOG2P, int CIN>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
+                                                                             FilterDev f, int run) {
+    using G = WaveGeom<LOG2P>;
+    using Q = typename PcmQuad<CIN>::type;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS, H = N1 / 2;
+    static_assert(N1 >= 2 && N2 % NT == 0, "walker needs P >= 2048");
+    __shared__ float2 s[G::LDS_ELEMS];
+    const StreamJob job = jobs[blockIdx.z];
+    const int whole = (int)min((long long)job.nblocks, job.nframes / P);
+    const int b0 = blockIdx.x * run;
+    if (b0 >= whole) return;
+    const int b1 = min(b0 + run, whole);
+    const int tid = threadIdx.x;
+    const Q* __restrict__ pcm = reinterpret_cast<const Q*>(job.in);     // quad p = frames 2p, 2p+1
+    const float2* __restrict__ tail_rd = reinterpret_cast<const float2*>(job.tail_rd);
+    float2* __restrict__ tail_wr = reinterpret_cast<float2*>(job.tail_wr);
+
+    // A block is P/2 quads = H rows of N2; this thread's quads of a block are (h, tid + c*NT).
+    Q prev[COLS][H], cur[COLS][H];
+    if (b0 == 0) {
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const int m = h * N2 + tid + c * NT;
+                quad_from_tails(prev[c][h], tail_rd[m], tail_rd[(CIN - 1) * (P / 2) + m]);
+            }
+    } else {
+        const Q* __restrict__ src = pcm + (size_t)(b0 - 1) * (P / 2) + tid;
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < H; ++h) prev[c][h] = src[h * N2 + c * NT];
+    }
+    {
+        const Q* __restrict__ src = pcm + (size_t)b0 * (P / 2) + tid;
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < H; ++h) cur[c][h] = src[h * N2 + c * NT];
+    }
+
+#pragma unroll 1
+    for (int b = b0; b < b1; ++b) {
+        const int slot = ring_slot(job.slot0, b, job.ring);
+        if (b == job.nblocks - 1) {                           // becomes the next call's x(n-1)
+#pragma unroll
+            for (int c = 0; c < COLS; ++c)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const int m = h * N2 + tid + c * NT;
+#pragma unroll
+                    for (int ch = 0; ch < CIN; ++ch) tail_wr[ch * (P / 2) + m] = quad_channel(cur[c][h], ch);
+                }
+        }
+#pragma unroll 1
+        for (int ch = 0; ch < CIN; ++ch) {
+            // Opaque copy of the thread index: keeps the (cheap) LDS / table address arithmetic
+            // of the FFT inside the loop instead of hoisted into ~100 loop-invariant registers.
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            // ---- stage A straight from the register quads ----
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                float2 v[N1];
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    v[h] = quad_channel(prev[c][h], ch);
+                    v[H + h] = quad_channel(cur[c][h], ch);
+                }
+                stage_a_column<LOG2P, false>(s, f.twa, t + c * NT, v);
+            }
+            if (ch == CIN - 1) {
+                // the quads are consumed: x(n) becomes x(n-1), and block n+1 starts to load now
+#pragma unroll
+                for (int c = 0; c < COLS; ++c)
+#pragma unroll
+                    for (int h = 0; h < H; ++h) prev[c][h] = cur[c][h];
+                if (b + 1 < b1) {
+                    const Q* __restrict__ src = pcm + (size_t)(b + 1) * (P / 2) + tid;
+#pragma unroll
+                    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+                        for (int h = 0; h < H; ++h) cur[c][h] = src[h * N2 + c * NT];
+                }
+            }
+            __syncthreads();
+            stage_b<LOG2P, false>(s, f.twb, t);
+            float2 wsp[SplitGeom<LOG2P>::CNT];
+            split_prefetch<LOG2P>(wsp, f.tw, t);
+            __syncthreads();
+            float2* row = job.fdl + ((size_t)ch * job.ring + slot) * P;
+            split_and_store<LOG2P>(s, wsp, t, row, 1.0f);
+            __syncthreads();                                  // the image is rewritten by the next stage A
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -485,9 +613,27 @@ hipError_t dispatch_log2p(int log2P, A&&... a) {
 
 template <int L>
 struct FwdLaunch {
-    static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, hipStream_t st) {
-        dim3 grid(max_blocks, f.cin, njobs), block(WaveGeom<L>::NT);
-        hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f);
+    // walker_ok: every stream of the launch has 16-byte aligned PCM (host-checked).
+    static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool walker_ok,
+                          bool any_partial, hipStream_t st) {
+        constexpr int NT = WaveGeom<L>::NT;
+        if constexpr (L >= 11) {
+            if (walker_ok && (f.cin == 1 || f.cin == 2)) {
+                // Blocks per workgroup: as long a walk as still leaves >= ~2 workgroups per CU.
+                int runlen = 8;
+                while (runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
+                dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
+                if (f.cin == 2) hipLaunchKernelGGL((forward_walker_kernel<L, 2>), grid, block, 0, st, jobs, f, runlen);
+                else hipLaunchKernelGGL((forward_walker_kernel<L, 1>), grid, block, 0, st, jobs, f, runlen);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess || !any_partial) return e;
+                dim3 grid2(1, f.cin, njobs);                  // the short last block of each stream, if any
+                hipLaunchKernelGGL(forward_kernel<L>, grid2, block, 0, st, jobs, f, 1);
+                return hipGetLastError();
+            }
+        }
+        dim3 grid(max_blocks, f.cin, njobs), block(NT);
+        hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f, 0);
         return hipGetLastError();
     }
 };
@@ -511,8 +657,9 @@ struct FilterLaunch {
 
 }  // namespace
 
-hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, hipStream_t st) {
-    return dispatch_log2p<FwdLaunch>(f.log2P, jobs, njobs, max_blocks, f, st);
+hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool walker_ok,
+                          bool any_partial, hipStream_t st) {
+    return dispatch_log2p<FwdLaunch>(f.log2P, jobs, njobs, max_blocks, f, walker_ok, any_partial, st);
 }
 
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
