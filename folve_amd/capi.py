@@ -65,6 +65,7 @@ ENGINE_SYMBOLS = [
     ("fe_stream_reset_peaks", _i, [_vp]),
     ("fe_stream_blocks_done", _ll, [_vp]),
     ("fe_batch_process", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _i]),
+    ("fe_batch_get_peaks", _i, [_pvp, _i, C.POINTER(_f), C.POINTER(_f)]),
     ("fe_engine_set_profiling", _i, [_vp, _i]),
     ("fe_engine_get_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
     ("fe_engine_reset_profile", _i, [_vp]),

@@ -688,6 +688,28 @@ int fe_stream_get_peaks(fe_stream* s, float* peak_signed, float* peak_abs) {
     return FE_OK;
 }
 
+int fe_batch_get_peaks(fe_stream* const* streams, int n, float* peak_signed, float* peak_abs) {
+    if (n < 0 || (n > 0 && !streams)) return fail(FE_ERR_PARAM, "bad arguments");
+    if (n == 0) return FE_OK;
+    fe_engine* e = streams[0]->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    std::vector<unsigned int> bits((size_t)n * 2, 0u);
+    for (int i = 0; i < n; ++i) {
+        if (!streams[i] || streams[i]->eng != e) return fail(FE_ERR_PARAM, "stream %d is null or on another engine", i);
+        HIP_TRY(hipMemcpyAsync(&bits[(size_t)i * 2], streams[i]->peaks, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                               e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n; ++i) {
+        float v[2];
+        memcpy(v, &bits[(size_t)i * 2], sizeof(v));
+        if (peak_signed) peak_signed[i] = v[0];
+        if (peak_abs) peak_abs[i] = v[1];
+    }
+    return FE_OK;
+}
+
 int fe_stream_reset_peaks(fe_stream* s) {
     if (!s) return fail(FE_ERR_PARAM, "null stream");
     fe_engine* e = s->eng;

@@ -62,6 +62,11 @@ fe_engine* DeviceRouter::EngineForDevice(int device) {
     return NULL;
 }
 
+fe_engine* DeviceRouter::EngineIfCreated(int slot) {
+    std::lock_guard<std::mutex> lk(mu_);
+    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)].engine : NULL;
+}
+
 void DeviceRouter::StreamOpened(fe_engine* e) {
     std::lock_guard<std::mutex> lk(mu_);
     for (Slot& s : slots_) if (s.engine == e) s.live++;

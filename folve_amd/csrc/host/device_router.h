@@ -30,6 +30,7 @@ public:
     // Engine of the least-loaded device (created on first use); NULL without a GPU.
     fe_engine* PickEngine();
     fe_engine* EngineForDevice(int device);
+    fe_engine* EngineIfCreated(int slot);      // NULL if that slot's engine was never needed
     void StreamOpened(fe_engine* e);
     void StreamClosed(fe_engine* e);
     int live_streams(int slot) const;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <string>
 
+#include "batch_scheduler.h"
 #include "device_router.h"
 #include "processor_pool.h"
 #include "sound_processor.h"
@@ -117,6 +118,25 @@ fh_processor* fh_pool_get_or_create(fh_pool* pool, const char* base_dir, int sam
 void fh_pool_return(fh_pool* pool, fh_processor* p) { PP(pool)->Return(SP(p)); }
 int fh_pool_pooled_count(fh_pool* pool, const char* config_path) {
     return static_cast<int>(PP(pool)->pooled_count(config_path));
+}
+
+void fh_batching_set(int enabled, int window_us, int max_batch) {
+    folve::BatchScheduler::SetEnabled(enabled != 0);
+    folve::BatchScheduler::Configure(window_us, max_batch);
+}
+int fh_batching_enabled(void) { return folve::BatchScheduler::Enabled(); }
+void fh_batching_stats(long long* requests, long long* batches, long long* largest) {
+    long long r = 0, b = 0, l = 0;
+    folve::DeviceRouter* router = folve::DeviceRouter::Default();
+    for (int d = 0; d < router->device_count(); ++d) {
+        fe_engine* e = router->EngineIfCreated(d);
+        if (!e) continue;
+        const folve::BatchScheduler::Stats st = folve::BatchScheduler::ForEngine(e)->stats();
+        r += st.requests; b += st.batches; if (st.largest > l) l = st.largest;
+    }
+    if (requests) *requests = r;
+    if (batches) *batches = b;
+    if (largest) *largest = l;
 }
 
 int fh_router_device_count(void) { return folve::DeviceRouter::Default()->device_count(); }

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 
+#include "batch_scheduler.h"
 #include "device_router.h"
 
 namespace folve {
@@ -95,7 +96,12 @@ void SoundProcessor::WriteProcessed(FrameSink* out, int sample_count) {
 void SoundProcessor::Process() {
     float peak_signed = 0.0f, peak_abs = 0.0f;
     if (input_pos_ > 0) {
-        const int rc = fe_stream_process(stream_, buffer_, input_pos_, buffer_, &peak_signed, &peak_abs);
+        // With batching on, the block joins whatever other files' threads submit within the
+        // collection window and runs as part of one launch; otherwise it is launched alone.
+        const int rc = BatchScheduler::Enabled()
+            ? BatchScheduler::ForEngine(zita_config_.engine)->Process(stream_, buffer_, input_pos_, buffer_,
+                                                                      &peak_signed, &peak_abs)
+            : fe_stream_process(stream_, buffer_, input_pos_, buffer_, &peak_signed, &peak_abs);
         if (rc != 0) {
             Logf("GPU convolution failed (%d): %s", rc, fe_last_error());
             memset(buffer_, 0, sizeof(float) * static_cast<size_t>(input_pos_) * output_channels());

@@ -620,8 +620,9 @@ struct FwdLaunch {
         if constexpr (L >= 11) {
             if (walker_ok && (f.cin == 1 || f.cin == 2)) {
                 // Blocks per workgroup: as long a walk as still leaves >= ~2 workgroups per CU.
-                int runlen = 8;
-                while (runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
+                static const char* rl = getenv("FOLVE_AMD_RUNLEN");
+                int runlen = rl ? atoi(rl) : 8;
+                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
                 if (f.cin == 2) hipLaunchKernelGGL((forward_walker_kernel<L, 2>), grid, block, 0, st, jobs, f, runlen);
                 else hipLaunchKernelGGL((forward_walker_kernel<L, 1>), grid, block, 0, st, jobs, f, runlen);

@@ -32,6 +32,9 @@ HOST_SYMBOLS = [
     ("fh_pool_get_or_create", _vp, [_vp, C.c_char_p, _i, _i, _i, C.c_char_p, _i]),
     ("fh_pool_return", None, [_vp, _vp]),
     ("fh_pool_pooled_count", _i, [_vp, C.c_char_p]),
+    ("fh_batching_set", None, [_i, _i, _i]),
+    ("fh_batching_enabled", _i, []),
+    ("fh_batching_stats", None, [C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
     ("fh_router_device_count", _i, []),
     ("fh_router_live_streams", _i, [_i]),
 ]
@@ -183,3 +186,14 @@ class ProcessorPool:
             self.close()
         except Exception:
             pass
+
+
+def set_batching(enabled, window_us=-1, max_batch=-1):
+    """Run-ahead batcher switch (folve::BatchScheduler)."""
+    _L().fh_batching_set(int(bool(enabled)), window_us, max_batch)
+
+
+def batching_stats():
+    r, b, l = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    _L().fh_batching_stats(C.byref(r), C.byref(b), C.byref(l))
+    return {"requests": r.value, "batches": b.value, "largest": l.value}

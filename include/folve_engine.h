@@ -120,6 +120,9 @@ long long fe_stream_blocks_done(const fe_stream *s);
 int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
                      float *const *out, int flags);
 
+/* Running peaks of n streams with one synchronisation (what the batcher hands back per block). */
+int fe_batch_get_peaks(fe_stream *const *streams, int n, float *peak_signed, float *peak_abs);
+
 /* ---- measurement hooks (bench.py: per-kernel HIP-event timing) ------------ */
 enum { FE_K_FORWARD = 0, FE_K_MAC = 1, FE_K_INVERSE = 2, FE_K_COUNT = 3 };
 int fe_engine_set_profiling(fe_engine *e, int on);

@@ -61,6 +61,13 @@ fh_processor *fh_pool_get_or_create(fh_pool *pool, const char *base_dir, int sam
 void fh_pool_return(fh_pool *pool, fh_processor *p);
 int fh_pool_pooled_count(fh_pool *pool, const char *config_path);
 
+/* run-ahead batcher (folve_amd/csrc/host/batch_scheduler.h): coalesce Process() calls of many file
+ * threads into one GPU launch.  window_us / max_batch < 0 keep the current value. */
+void fh_batching_set(int enabled, int window_us, int max_batch);
+int fh_batching_enabled(void);
+/* totals over all GPUs since process start */
+void fh_batching_stats(long long *requests, long long *batches, long long *largest);
+
 /* the process-wide GPU sharder */
 int fh_router_device_count(void);
 int fh_router_live_streams(int slot);

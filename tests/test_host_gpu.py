@@ -180,3 +180,35 @@ def test_processors_run_concurrently_from_threads(oracle, tmp_path):
         assert oracle.rms(y - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
     assert H._L().fh_router_device_count() >= 1
     assert H._L().fh_router_live_streams(0) >= len(sigs)
+
+
+def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
+    """folve::BatchScheduler: Process() calls of many file threads become one GPU launch (SURVEY §8f-2)."""
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    conf = os.path.join(d, "filter-44100.conf")
+    sigs = [seeded_input(70 + i, 5 * 8192 + 64 * i, 2) for i in range(12)]
+
+    def run_all():
+        procs = [H.SoundProcessor.create(conf, 44100, 2) for _ in sigs]
+        outs = [None] * len(sigs)
+        th = [threading.Thread(target=lambda i=i: outs.__setitem__(i, procs[i].run(sigs[i]))) for i in range(len(sigs))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return outs, [p.max_output_value() for p in procs]
+
+    plain, peaks_plain = run_all()
+    before = H.batching_stats()
+    H.set_batching(True, window_us=2000, max_batch=64)
+    try:
+        batched, peaks_batched = run_all()
+    finally:
+        H.set_batching(False)
+    after = H.batching_stats()
+    nreq = after["requests"] - before["requests"]
+    nbat = after["batches"] - before["batches"]
+    assert nreq == sum((len(x) + 8191) // 8192 for x in sigs)
+    assert nbat < nreq and after["largest"] >= 2                 # blocks of different files shared launches
+    for a, b in zip(plain, batched):
+        assert np.array_equal(a, b)                                # same kernels, same per-stream arithmetic
+    assert peaks_plain == peaks_batched
+    assert oracle.rms(batched[3] - oracle.linear_convolution_f64(sigs[3], hs, 2)) <= TOL
