@@ -55,20 +55,30 @@ def main():
     import folve_amd as fa
     from folve_amd.capi import BatchPlan, FE_ASYNC, FE_DEVICE_PTRS
 
+    from folve_amd import sharding
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FOLVE_BENCH_DEVICE / FOLVE_BENCH_BACKEND exist so that the N > 1 code path can be exercised on a
+    # one-GPU box (all ranks on one device, gloo); the driver's runs use one rank per GPU over RCCL.
+    dev = int(os.environ.get("FOLVE_BENCH_DEVICE", local_rank if world > 1 else 0))
+    backend = os.environ.get("FOLVE_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
-    dev = torch.cuda.current_device()
+    red_dev = torch.device("cuda", dev) if backend == "nccl" else torch.device("cpu")
+    # streams are sharded by index, as the pool hands out processors: gpu = stream % world
+    my_streams = sharding.shard_streams(args.streams * world, world, rank)
+    assert len(my_streams) == args.streams
 
     S, T, C, size = args.streams, args.blocks, args.channels, args.taps
     ts = torch.cuda.Stream()
@@ -86,7 +96,7 @@ def main():
         xs, ys = [], []
         for s in range(S):
             g = torch.Generator(device="cuda")
-            g.manual_seed(100 + rank * S + s)
+            g.manual_seed(100 + my_streams[s])
             xs.append(torch.rand(T * P, C, device="cuda", generator=g) * 2 - 1)   # U(-1, 1)
             ys.append(torch.empty(T * P, C, device="cuda"))
     plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S,
@@ -108,10 +118,7 @@ def main():
         plan.run()
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tdt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
+    _, dt, _ = sharding.aggregate_throughput(S * T * P * args.steps, dt, dist, red_dev)   # max over ranks
 
     frames_per_step_gpu = S * T * P
     frames_total = frames_per_step_gpu * world * args.steps
