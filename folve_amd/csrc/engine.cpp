@@ -180,7 +180,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     std::vector<fk::StreamJob> jobs;
     jobs.reserve(items.size());
     int yunits = 0, max_blocks = 0;
-    bool walker_ok = true, any_partial = false;
+    bool walker_ok = true, walker_out_ok = true, any_partial = false;
     for (Item& it : items) {
         if (it.left <= 0) continue;
         fe_stream* s = it.s;
@@ -196,6 +196,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         j.peaks = s->peaks;
         j.nframes = take;
         if (reinterpret_cast<uintptr_t>(it.in) & 15) walker_ok = false;
+        if (reinterpret_cast<uintptr_t>(it.out) & 15) walker_out_ok = false;
         if (take % P) any_partial = true;
         j.nblocks = (int)((take + P - 1) / P);
         j.slot0 = s->slot0;
@@ -248,7 +249,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
     HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, lane.Y, max_blocks, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
-    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, lane.Y, st));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, lane.Y, walker_out_ok, st));
     if (prof) {
         HIP_TRY(hipEventRecord(e->pev[3], st));
         HIP_TRY(hipEventSynchronize(e->pev[3]));

@@ -59,7 +59,7 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
                       int time_tile, hipStream_t st);
 // K3: spectra -> PCM (last P of each 2P window) + peaks.  grid (max blocks, cout, jobs)
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          hipStream_t st);
+                          bool walker_ok, hipStream_t st);
 struct FftTables { const float2* tw; const float2* twa; const float2* twb; };
 // K0: time-domain taps [ndata][K*P] -> H [ndata][K][P] (scaled by 1/(2P)).
 hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const FftTables& t,

@@ -419,14 +419,167 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     }
 }
 
+// ---------------------------------------------------------------------------
+// K3, fast form ("pair-walker"): mono / stereo output, P = 8192.
+// grid (runs of `run` consecutive blocks, 1, streams)
+//
+// One workgroup owns the stream's output channel pair and walks `run` consecutive
+// blocks.  The fold twiddles e^(-i*pi*k/P) depend only on the thread's columns, so
+// they are loaded once and stay in registers for the whole walk; the Y row of the
+// next FFT is requested as soon as the fold has consumed the current one; the first
+// channel's samples wait in registers for the second's, and the block leaves as
+// whole (L0, R0, L1, R1) quads — 16 bytes per lane, full lines — instead of two
+// workgroups interleaving 4-byte stores.
+// ---------------------------------------------------------------------------
+template <int LOG2P, int COUT>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(const StreamJob* __restrict__ jobs,
+                                                                             FilterDev f,
+                                                                             const float2* __restrict__ Y, int run) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
+    static_assert(N1 >= 2 && NT == N2 / 2, "walker needs P = 8192 (one column pair per thread)");
+    constexpr int OUTS = (P / 2) / NT;                        // output complex samples per thread (8)
+    __shared__ float2 s[G::LDS_ELEMS];
+    const StreamJob job = jobs[blockIdx.z];
+    const int b0 = blockIdx.x * run;
+    if (b0 >= job.nblocks) return;
+    const int b1 = min(b0 + run, job.nblocks);
+    const int tid = threadIdx.x;
+    const float2* __restrict__ tw = f.tw;
+    // column pair of this thread: (p, N2 - p); thread 0 owns the self-paired columns 0 and N2/2
+    const int ca = tid, cb = (tid == 0) ? N2 / 2 : N2 - tid;
+
+    float2 wa[N1];                                            // e^(-i*pi*k/P), k = n1*N2 + ca
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) wa[n1] = tw[n1 * N2 + ca];
+
+    const int nunits = (b1 - b0) * COUT;                      // unit u = (block, channel), channel fastest
+    auto row_of = [&](int u) {
+        const int b = b0 + u / COUT, o = u % COUT;
+        return Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P;
+    };
+    float2 ya[N1], yb[N1];
+    {
+        const float2* __restrict__ y = row_of(0);
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) { ya[n1] = y[n1 * N2 + ca]; yb[n1] = y[n1 * N2 + cb]; }
+    }
+    float* __restrict__ out = job.out;
+    float pk_s = 0.0f, pk_a = 0.0f;
+    float2 zl[OUTS];                                          // first channel's samples of the block
+
+#pragma unroll 1
+    for (int u = 0; u < nunits; ++u) {
+        int t = tid;                                          // opaque copy: keeps address arithmetic in the loop
+        asm volatile("" : "+v"(t));
+        const int b = b0 + u / COUT, o = u % COUT;
+        // ---- Hermitian fold in registers (see inverse_kernel) ----
+        float2 za[N1], zb[N1];
+        if (t != 0) {
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) {
+                const float2 a = ya[n1], bb = yb[N1 - 1 - n1];
+                const float2 e = float2{a.x + bb.x, a.y - bb.y};
+                const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                const float2 oo = cmulc(dd, wa[n1]);
+                za[n1] = float2{e.x - oo.y, e.y + oo.x};
+                zb[N1 - 1 - n1] = float2{e.x + oo.y, -e.y + oo.x};
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) {
+                if (n1 == 0) {
+                    const float2 y0 = ya[0];
+                    za[0] = float2{y0.x + y0.y, y0.x - y0.y};
+                } else {
+                    const float2 a = ya[n1], bb = ya[N1 - n1];
+                    const float2 e = float2{a.x + bb.x, a.y - bb.y};
+                    const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                    const float2 oo = cmulc(dd, wa[n1]);
+                    za[n1] = float2{e.x - oo.y, e.y + oo.x};
+                }
+                const float2 a = yb[n1], bb = yb[N1 - 1 - n1];
+                const float2 e = float2{a.x + bb.x, a.y - bb.y};
+                const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                const float2 oo = cmulc(dd, tw[n1 * N2 + N2 / 2]);
+                zb[n1] = float2{e.x - oo.y, e.y + oo.x};
+            }
+        }
+        if (u + 1 < nunits) {                                 // the next row flies during this FFT
+            const float2* __restrict__ y = row_of(u + 1);
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) { ya[n1] = y[n1 * N2 + ca]; yb[n1] = y[n1 * N2 + cb]; }
+        }
+        stage_a_column<LOG2P, true>(s, f.twa, t, za);
+        stage_a_column<LOG2P, true>(s, f.twa, (t == 0) ? N2 / 2 : N2 - t, zb);
+        __syncthreads();
+        stage_b<LOG2P, true>(s, f.twb, t);
+        __syncthreads();
+        // ---- transposed read: consecutive lanes take consecutive output frames ----
+        const long long fb = (long long)b * P;
+        const bool whole = (fb + P <= job.nframes);
+        if (COUT == 2 && o == 0) {
+#pragma unroll
+            for (int c = 0; c < OUTS; ++c) zl[c] = s[G::at(P / 2 + t + c * NT)];
+        } else {
+#pragma unroll
+            for (int c = 0; c < OUTS; ++c) {
+                const int q = P / 2 + t + c * NT;             // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
+                const float2 z = s[G::at(q)];
+                const long long fr = fb + 2 * q - P;
+                if constexpr (COUT == 2) {
+                    const float2 l = zl[c];
+                    if (whole) {
+                        *reinterpret_cast<float4*>(out + fr * 2) = float4{l.x, z.x, l.y, z.y};
+                        pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
+                        pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
+                    } else {
+                        if (fr < job.nframes) {
+                            out[fr * 2] = l.x; out[fr * 2 + 1] = z.x;
+                            pk_s = fmaxf(pk_s, fmaxf(l.x, z.x));
+                            pk_a = fmaxf(pk_a, fmaxf(fabsf(l.x), fabsf(z.x)));
+                        }
+                        if (fr + 1 < job.nframes) {
+                            out[fr * 2 + 2] = l.y; out[fr * 2 + 3] = z.y;
+                            pk_s = fmaxf(pk_s, fmaxf(l.y, z.y));
+                            pk_a = fmaxf(pk_a, fmaxf(fabsf(l.y), fabsf(z.y)));
+                        }
+                    }
+                } else {
+                    if (whole) {
+                        *reinterpret_cast<float2*>(out + fr) = z;
+                        pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
+                        pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
+                    } else {
+                        if (fr < job.nframes) { out[fr] = z.x; pk_s = fmaxf(pk_s, z.x); pk_a = fmaxf(pk_a, fabsf(z.x)); }
+                        if (fr + 1 < job.nframes) { out[fr + 1] = z.y; pk_s = fmaxf(pk_s, z.y); pk_a = fmaxf(pk_a, fabsf(z.y)); }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                      // the image is rewritten by the next stage A
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pk_s = fmaxf(pk_s, __shfl_xor(pk_s, off, 64));
+        pk_a = fmaxf(pk_a, __shfl_xor(pk_a, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        atomicMax(job.peaks + 0, __float_as_uint(pk_s));
+        atomicMax(job.peaks + 1, __float_as_uint(pk_a));
+    }
+}
+
 // Packed bin 0 = (DC, Nyquist): two real products, not a complex one.  Done by
 // the first TT threads of the workgroup that owns bin 0, one output block each.
 template <int TT>
 __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const FilterDev& f, float2* __restrict__ Y,
                                                 int t0, int pe0, int pe1, size_t yrow0) {
-    if (blockIdx.x != 0 || (int)threadIdx.x >= TT || t0 + (int)threadIdx.x >= job.nblocks) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;         // first wavefront of the workgroup owning bin 0
     const int P = f.P, K = f.K, ring = job.ring;
-    const int tt = threadIdx.x;
+    constexpr int G = 64 / TT;                                // lanes per output block (TT <= 32)
+    const int tt = threadIdx.x % TT, g = threadIdx.x / TT;    // this lane: output tt, partitions g, g+G, ...
     float re = 0.f, im = 0.f;
     for (int pe = pe0; pe < pe1; ++pe) {
         const PathEntry pth = f.paths[pe];
@@ -434,7 +587,7 @@ __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const Filt
         const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
         const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
         const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
-        for (int j = K - 1; j >= 0; --j) {
+        for (int j = g; j < K; j += G) {
             const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
             if (!on) continue;
             const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
@@ -444,7 +597,12 @@ __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const Filt
             im = fmaf(x.y, h.y, im);
         }
     }
-    Y[(yrow0 + tt) * P] = float2{re, im};
+#pragma unroll
+    for (int off = TT; off < 64; off <<= 1) {                 // sum over the G partition groups
+        re += __shfl_xor(re, off, 64);
+        im += __shfl_xor(im, off, 64);
+    }
+    if (g == 0 && t0 + tt < job.nblocks) Y[(yrow0 + tt) * P] = float2{re, im};
 }
 
 // ---------------------------------------------------------------------------
@@ -552,11 +710,17 @@ __global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restr
         // requested at step j (keeps >= 40 KB per CU in flight at 2-4 waves/SIMD)
         static_assert(TT % D == 0, "prefetch ring must divide the unroll");
         V hq[D], xq[D];
+        // Row cursors advance by one row per step (no per-step modulo / multiply): the H row
+        // pointer moves forward, the X ring slot moves backward with wrap-around.
+        int xs = ring_slot(job.slot0, t0 - 1, ring);          // ring slot of X(t0 - 1 - d)
+        const V* hp = Hd;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (d < K) {
-                hq[d] = Hd[(size_t)d * PV];
-                xq[d] = X[(size_t)ring_slot(job.slot0, t0 - d - 1, ring) * PV];
+                hq[d] = *hp;
+                xq[d] = X[(size_t)xs * PV];
+                hp += PV;
+                xs = (xs == 0) ? ring - 1 : xs - 1;
             }
         }
         for (int j0 = 0; j0 < K; j0 += TT) {
@@ -567,8 +731,10 @@ __global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restr
                     const V h = hq[jj % D];
                     const V xnew = xq[jj % D];
                     if (j + D < K) {
-                        hq[jj % D] = Hd[(size_t)(j + D) * PV];
-                        xq[jj % D] = X[(size_t)ring_slot(job.slot0, t0 - j - D - 1, ring) * PV];
+                        hq[jj % D] = *hp;
+                        xq[jj % D] = X[(size_t)xs * PV];
+                        hp += PV;
+                        xs = (xs == 0) ? ring - 1 : xs - 1;
                     }
                     const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
                     if (on) {
@@ -618,7 +784,8 @@ struct FwdLaunch {
                           bool any_partial, hipStream_t st) {
         constexpr int NT = WaveGeom<L>::NT;
         if constexpr (L >= 11) {
-            if (walker_ok && (f.cin == 1 || f.cin == 2)) {
+            // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
+            if (walker_ok && (f.cin == 1 || f.cin == 2) && (long long)njobs * max_blocks >= 256) {
                 // Blocks per workgroup: as long a walk as still leaves >= ~2 workgroups per CU.
                 static const char* rl = getenv("FOLVE_AMD_RUNLEN");
                 int runlen = rl ? atoi(rl) : 8;
@@ -640,9 +807,22 @@ struct FwdLaunch {
 };
 template <int L>
 struct InvLaunch {
+    // walker_ok: every stream's output pointer is 16-byte aligned (host-checked).
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          hipStream_t st) {
-        dim3 grid(max_blocks, f.cout, njobs), block(WaveGeom<L>::NT);
+                          bool walker_ok, hipStream_t st) {
+        constexpr int NT = WaveGeom<L>::NT;
+        if constexpr (L == 13) {      // P = 8192 (every filter longer than 4096 taps): one column pair per thread
+            if (walker_ok && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
+                static const char* rl = getenv("FOLVE_AMD_RUNLEN");
+                int runlen = rl ? atoi(rl) : 8;
+                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
+                dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
+                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2>), grid, block, 0, st, jobs, f, Y, runlen);
+                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1>), grid, block, 0, st, jobs, f, Y, runlen);
+                return hipGetLastError();
+            }
+        }
+        dim3 grid(max_blocks, f.cout, njobs), block(NT);
         hipLaunchKernelGGL(inverse_kernel<L>, grid, block, 0, st, jobs, f, Y);
         return hipGetLastError();
     }
@@ -664,8 +844,8 @@ hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, cons
 }
 
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          hipStream_t st) {
-    return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, st);
+                          bool walker_ok, hipStream_t st) {
+    return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, walker_ok, st);
 }
 
 hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const FftTables& t,
