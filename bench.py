@@ -139,15 +139,17 @@ def main():
     dominant = max(kms, key=kms.get)
     dom_bytes = ab[dominant] * units_per_launch
     achieved = dom_bytes / (kms[dominant] * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
+    # process, so the value comes from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/traffic.json, made by tools/profile.sh); null for shapes that were not profiled.
+    traffic, tj = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = "S%d_T%d_K%d_C%d" % (S, T, K, C)
-            traffic = tj.get(key, {}).get(dominant)
+            traffic = tj.get("S%d_T%d_K%d_C%d" % (S, T, K, C), {}).get(dominant)
         except Exception:
-            traffic = None
+            traffic, tj = None, None
     roofline = {"bound": "hbm", "kernel": "K2 " + dominant if dominant == "mac" else dominant,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -157,7 +159,8 @@ def main():
                          "achieved": round(ab["total"] * units_per_launch * world * args.steps / dt / 1e9, 1),
                          "frac": round(ab["total"] * units_per_launch * world * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4)}}
 
-    # streaming form (one block per stream per call = SoundProcessor::Process granularity)
+    # streaming form (one block per stream per call = SoundProcessor::Process granularity): here K2
+    # really streams K spectra per block, so algorithmic and measured bytes coincide
     streaming = None
     if world == 1:
         st1 = [flt.open_stream(1) for _ in range(S)]
@@ -172,9 +175,21 @@ def main():
             plan1.run()
         sync()
         d1 = (time.perf_counter() - t1) / n1
+        eng.set_profiling(True)
+        eng.reset_profile()
+        for _ in range(20):
+            plan1.run()
+        sync()
+        p1 = eng.get_profile()
+        eng.set_profiling(False)
+        mac1_ms = p1["mac"]["ms"] / max(1, p1["mac"]["launches"])
+        mac1_gbs = ab["mac"] * S * C / (mac1_ms * 1e-3) / 1e9
         streaming = {"blocks_per_call": 1, "ms_per_step": round(d1 * 1e3, 4),
                      "msamples_per_s": round(S * P * C / d1 / 1e6, 1),
-                     "path_frac": round(ab["total"] * S * C / d1 / 1e9 / HBM_PEAK_GBS, 4)}
+                     "path_frac": round(ab["total"] * S * C / d1 / 1e9 / HBM_PEAK_GBS, 4),
+                     "mac_kernel_ms": round(mac1_ms, 4), "mac_achieved_GBs": round(mac1_gbs, 1),
+                     "mac_frac": round(mac1_gbs / HBM_PEAK_GBS, 4),
+                     "mac_traffic": (tj or {}).get("S%d_T1_K%d_C%d" % (S, K, C), {}).get("mac")}
         for s_ in st1:
             s_.close()
 

@@ -65,7 +65,7 @@ struct fe_engine {
     };
     Lane lanes[2];
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    int max_lanes = 2;
+    int max_lanes = 1;                   // FOLVE_AMD_LANES=2 turns the fork on (measured: ~1 % on MI355X)
     long long split_min_units = 512;     // block-channels below which a batch stays on one lane
     // rotating pinned/device buffers for job descriptors (async uploads)
     fk::StreamJob* jobs_host[kJobSlots] = {};
