@@ -199,8 +199,8 @@ def main():
         cores = os.cpu_count() or 1
         nthreads = cores
         nstreams = nthreads
-        tprobe = O.bench_streams(nstreams, 1, nthreads, C, C, size, 3)
-        nblocks = int(max(2, min(1024, args.cpu_seconds / max(tprobe, 1e-3))))
+        tprobe = O.bench_streams(nstreams, 4, nthreads, C, C, size, 3) / 4.0      # seconds per block round
+        nblocks = int(max(4, min(4096, args.cpu_seconds / max(tprobe, 1e-4))))
         tcpu = O.bench_streams(nstreams, nblocks, nthreads, C, C, size, 3)
         cpu = {"value": round(nstreams * nblocks * P * C / tcpu / 1e6, 2), "unit": "Msamples/s", "cores": nthreads,
                "kind": "port",
