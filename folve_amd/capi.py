@@ -21,7 +21,8 @@ class FolveError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfolve_amd.so")
+    # FOLVE_AMD_LIB: load another build of the same library (the sanitizer build of tools/asan_host.sh)
+    return os.environ.get("FOLVE_AMD_LIB") or os.path.join(_HERE, "libfolve_amd.so")
 
 
 def build_library(force=False):

@@ -212,3 +212,46 @@ def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
         assert np.array_equal(a, b)                                # same kernels, same per-stream arithmetic
     assert peaks_plain == peaks_batched
     assert oracle.rms(batched[3] - oracle.linear_convolution_f64(sigs[3], hs, 2)) <= TOL
+
+
+def test_pool_churn_under_threads_with_two_filters_and_batching(oracle, tmp_path):
+    """Open/return/reuse churn from several threads, two configurations at once, batcher on."""
+    d_echo = make_echo_filter_dir(tmp_path)
+    d_low = make_pass_filter_dir(tmp_path, "lowpass")
+    pool = H.ProcessorPool(3)
+    g = golden("lowpass")
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for it in range(6):
+                use_echo = bool((seed + it) & 1)
+                p, err = pool.get_or_create(d_echo if use_echo else d_low, 44100, 2, 16)
+                assert p is not None, err
+                n = int(rng.integers(1, 3 * 8192))
+                x = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+                y = p.run(x)
+                if use_echo:
+                    exp = 0.7 * x.astype(np.float64)
+                    if n > 22050:
+                        exp[22050:] += 0.3 * x[:-22050]
+                else:
+                    taps = g["taps_int16"]
+                    h = np.float32(g["gain"]) * (taps[:, 0].astype(np.float32) / np.float32(32768.0))
+                    exp = np.stack([np.convolve(x[:, c].astype(np.float64), h.astype(np.float64))[:n] for c in range(2)], 1)
+                assert oracle.rms(y - exp) <= TOL
+                pool.give_back(p)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    H.set_batching(True, window_us=300, max_batch=32)
+    try:
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        H.set_batching(False)
+    assert not errors, errors
+    assert pool.pooled_count(os.path.join(d_echo, "filter-44100.conf")) <= 3
+    assert pool.pooled_count(os.path.join(d_low, "filter-44100.conf")) <= 3
