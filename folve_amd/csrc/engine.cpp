@@ -64,7 +64,7 @@ struct fe_engine {
         size_t Y_bytes = 0;
     };
     Lane lanes[2];
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr, stagger_ev = nullptr;
     int max_lanes = 1;                   // FOLVE_AMD_LANES=2 turns the fork on (measured: ~1 % on MI355X)
     long long split_min_units = 512;     // block-channels below which a batch stays on one lane
     // rotating pinned/device buffers for job descriptors (async uploads)
@@ -173,7 +173,9 @@ struct Item {
 };
 
 // One launch round over streams that share a filter.
-int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane_id = 0) {
+// stagger: 0 none; 1 record e->stagger_ev after this round's K1; 2 wait for it before this round's K1
+// (a forked batch runs lane 1 one kernel behind lane 0, so a MAC always runs beside an FFT kernel).
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane_id = 0, int stagger = 0) {
     fe_engine::Lane& lane = e->lanes[lane_id];
     hipStream_t st = lane.st;
     const int P = f->P;
@@ -245,7 +247,9 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     const int nj = (int)jobs.size();
     const bool prof = e->profiling;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
+    if (stagger == 2) HIP_TRY(hipStreamWaitEvent(st, e->stagger_ev, 0));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, walker_ok, any_partial, st));
+    if (stagger == 1) HIP_TRY(hipEventRecord(e->stagger_ev, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
     HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, lane.Y, max_blocks, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
@@ -323,6 +327,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             HIP_TRY(hipStreamCreateWithFlags(&e->lanes[1].st, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->stagger_ev, hipEventDisableTiming));
         }
         std::vector<Item> half[2];
         for (size_t k = 0; k < group.size(); ++k) half[k >= (group.size() + 1) / 2].push_back(group[k]);
@@ -330,8 +335,9 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         HIP_TRY(hipStreamWaitEvent(e->lanes[1].st, e->fork_ev, 0));
         bool any0 = true, any1 = true;
         while (any0 || any1) {
-            if (any0) { int rc = launch_round(e, f, half[0], &any0, 0); if (rc) return rc; }
-            if (any1) { int rc = launch_round(e, f, half[1], &any1, 1); if (rc) return rc; }
+            const bool both = any0 && any1;
+            if (any0) { int rc = launch_round(e, f, half[0], &any0, 0, both ? 1 : 0); if (rc) return rc; }
+            if (any1) { int rc = launch_round(e, f, half[1], &any1, 1, both ? 2 : 0); if (rc) return rc; }
         }
         HIP_TRY(hipEventRecord(e->join_ev, e->lanes[1].st));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
@@ -414,6 +420,7 @@ static void engine_release(fe_engine* e) {
     if (e->lanes[1].st) (void)hipStreamDestroy(e->lanes[1].st);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     if (e->join_ev) (void)hipEventDestroy(e->join_ev);
+    if (e->stagger_ev) (void)hipEventDestroy(e->stagger_ev);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     for (int i = 0; i < kJobSlots; ++i) {
