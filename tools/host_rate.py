@@ -23,3 +23,15 @@ for _ in range(n):
     plan.run()
 dt = (time.perf_counter() - t0) / n
 print("host-pointer batch: %.2f ms/step, %.1f Msamples/s (pageable host memory, H2D + K1-K3 + D2H)" % (dt * 1e3, S * T * P * 2 / dt / 1e6))
+
+# one block per call through the exact SoundProcessor::Process path (host pointers, synchronous, peaks fetched)
+st = flt.open_stream(1)
+x = xs[0][:P]
+for _ in range(40):
+    st.process(x)
+t0 = time.perf_counter(); n = 200
+for _ in range(n):
+    st.process(x)
+dt = (time.perf_counter() - t0) / n
+print("fe_stream_process, one stereo block per call: %.1f us/block = %.1f Mframes/s = %.0fx real time at 44.1 kHz" % (
+    dt * 1e6, P / dt / 1e6, P / dt / 44100))
