@@ -267,8 +267,9 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     return FE_OK;
 }
 
+// peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
-                   const long long* nframes, float* const* out, int flags) {
+                   const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr) {
     const bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
     const bool async = device_ptrs && (flags & FE_ASYNC);
     HIP_TRY(hipSetDevice(e->device));
@@ -349,6 +350,11 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             if (no) HIP_TRY(hipMemcpyAsync(out[i], e->stage_out + oo, no * sizeof(float), hipMemcpyDeviceToHost, e->stream));
             oo += (no + 3) & ~(size_t)3;
         }
+    }
+    if (peaks_out) {
+        for (int i = 0; i < n; ++i)
+            HIP_TRY(hipMemcpyAsync(peaks_out + 2 * i, streams[i]->peaks, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                   e->stream));
     }
     if (!async) HIP_TRY(hipStreamSynchronize(e->stream));
     return FE_OK;
@@ -751,10 +757,22 @@ int fe_stream_process(fe_stream* s, const float* in, int valid_frames, float* ou
                       float* peak_abs) {
     if (!s) return fail(FE_ERR_PARAM, "null stream");
     if (valid_frames < 1 || valid_frames > s->f->P) return fail(FE_ERR_PARAM, "valid_frames must be in 1..block size");
-    int rc = fe_stream_process_blocks(s, in, valid_frames, out);
+    if (!in || !out) return fail(FE_ERR_PARAM, "null buffer");
+    fe_stream* ss[1] = {s};
+    const float* ii[1] = {in};
+    float* oo[1] = {out};
+    long long nn[1] = {valid_frames};
+    unsigned int bits[2] = {0u, 0u};
+    fe_engine* e = s->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    // one synchronisation for the block and its peaks
+    const int rc = process_locked(e, ss, 1, ii, nn, oo, FE_HOST_PTRS, (peak_signed || peak_abs) ? bits : nullptr);
     if (rc) return rc;
-    if (peak_signed || peak_abs) rc = fe_stream_get_peaks(s, peak_signed, peak_abs);
-    return rc;
+    float v[2];
+    memcpy(v, bits, sizeof(v));
+    if (peak_signed) *peak_signed = v[0];
+    if (peak_abs) *peak_abs = v[1];
+    return FE_OK;
 }
 
 // ---- measurement hooks ------------------------------------------------------
