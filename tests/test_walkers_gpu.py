@@ -1,0 +1,85 @@
+"""GPU: batches large enough (>= 256 blocks per launch) to take the pair-walker kernels
+(forward_walker_kernel<11|12|13, 1|2>, inverse_walker_kernel<13, 1|2>), against the oracle and
+against the general kernels (same streams run in small batches)."""
+import numpy as np
+import pytest
+
+import folve_amd as fa
+from helpers import dense_taps, make_pair
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rms(a):
+    a = np.asarray(a, np.float64)
+    return float(np.sqrt(np.mean(a * a)))
+
+
+@pytest.mark.parametrize("channels,size,nstreams,nblocks", [
+    (2, 20000, 16, 17),     # P = 8192, K = 3: forward_walker<13,2> + inverse_walker<13,2>
+    (1, 20000, 16, 17),     # mono: <13,1> both
+    (2, 4000, 16, 20),      # P = 4096: forward_walker<12,2>, general inverse
+    (1, 3000, 20, 16),      # P = 4096 mono
+    (2, 1500, 32, 12),      # P = 2048: forward_walker<11,2>
+    (1, 2000, 16, 20),      # P = 2048 mono
+])
+def test_walker_batches_match_oracle_and_general_kernels(engine, oracle, channels, size, nstreams, nblocks):
+    rng = np.random.default_rng(size + channels)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(channels)}
+    if channels == 2:
+        paths[(0, 1)] = [(7, (rng.standard_normal(size // 3) * 0.02).astype(np.float32))]   # a cross path
+    sp, flt, _ = make_pair(engine, oracle, channels, channels, size, paths)
+    P = flt.block_size
+    assert nstreams * nblocks >= 256
+    lens = [nblocks * P - (0 if s % 3 else 1234 + s) for s in range(nstreams)]              # some ragged tails
+    xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
+    big = [flt.open_stream(nblocks) for _ in range(nstreams)]
+    ys = fa.batch_process(big, xs)                                   # one launch round: walkers
+    hd = dense_taps(paths, size)
+    for s in (0, 1, nstreams - 1):
+        sp.reset()
+        yo = sp.run(xs[s])
+        assert _rms(ys[s] - yo) <= TOL
+        y64 = oracle.linear_convolution_f64(xs[s], hd, channels)
+        assert _rms(ys[s] - y64) <= TOL and _rms(ys[s] - y64) / _rms(y64) <= TOL
+    # the same streams through the general kernels (single stream, few blocks per call)
+    for s in (2, 5):
+        small = flt.open_stream(2)
+        yg = small.process_blocks(xs[s])
+        assert _rms(ys[s] - yg) <= 2e-6
+    # state carries across walker calls: second call continues the convolution
+    more = [rng.uniform(-1, 1, (3 * P + 5, channels)).astype(np.float32) for _ in range(nstreams)]
+    ys2 = fa.batch_process(big, more)
+    full = oracle.linear_convolution_f64(np.concatenate([np.pad(xs[1], ((0, nblocks * P - lens[1]), (0, 0))), more[1]]),
+                                         hd, channels)
+    assert _rms(ys2[1] - full[nblocks * P:]) <= TOL
+    pk = big[1].peaks()
+    both = np.concatenate([ys[1], ys2[1]])
+    assert abs(pk[0] - max(0.0, float(both.max()))) <= 1e-6 and abs(pk[1] - float(np.abs(both).max())) <= 1e-6
+
+
+def test_unaligned_device_pointers_fall_back_to_general_kernels(engine, oracle):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(9)
+    size = 20000
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    _, flt, _ = make_pair(engine, oracle, 2, 2, size, paths)
+    P, S, T = flt.block_size, 16, 16
+    x = rng.uniform(-1, 1, (S, T * P + 1, 2)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    out_a = torch.zeros(S, T * P, 2, device="cuda")
+    out_u = torch.zeros(S, T * P + 1, 2, device="cuda")
+    sa = [flt.open_stream(T) for _ in range(S)]
+    su = [flt.open_stream(T) for _ in range(S)]
+    aligned_in = [xd[s, :T * P].contiguous() for s in range(S)]
+    fa.batch_process(sa, aligned_in, [out_a[s] for s in range(S)], device=True)             # walkers
+    # views starting one frame (8 bytes) into the buffers: not 16-byte aligned
+    fa.batch_process(su, [xd[s, 1:] for s in range(S)], [out_u[s, 1:] for s in range(S)], device=True)
+    ya = out_a.cpu().numpy()
+    yu = out_u.cpu().numpy()[:, 1:]
+    hd = dense_taps(paths, size)
+    y64 = oracle.linear_convolution_f64(x[3, :T * P], hd, 2)
+    assert _rms(ya[3] - y64) <= TOL
+    y64u = oracle.linear_convolution_f64(x[3, 1:], hd, 2)
+    assert _rms(yu[3] - y64u) <= TOL
