@@ -128,6 +128,24 @@ FK_HD int phys(int i) { return i + (i >> 4); }
 
 #if defined(__HIPCC__)
 
+// ---- global-memory accessors -------------------------------------------------
+// A pointer that was itself read from memory (the StreamJob descriptors: PCM, FDL rows,
+// tails) is a GENERIC pointer to the compiler, and plain dereferences become flat_load /
+// flat_store: those also tick lgkmcnt and return out of order, so every LDS wait in the FFT
+// kernels would wait for them too.  These helpers cast to the global address space first
+// (global_load / global_store, vmcnt only).
+#define FK_GLOBAL __attribute__((address_space(1)))
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+FK_D float gld(const float* p) { return *(const FK_GLOBAL float*)p; }
+FK_D float2 gld(const float2* p) { const v2f v = *(const FK_GLOBAL v2f*)p; return float2{v.x, v.y}; }
+FK_D float4 gld(const float4* p) { const v4f v = *(const FK_GLOBAL v4f*)p; return float4{v.x, v.y, v.z, v.w}; }
+FK_D v2f gld_v2(const float2* p) { return *(const FK_GLOBAL v2f*)p; }
+FK_D void gst(float* p, float v) { *(FK_GLOBAL float*)p = v; }
+FK_D void gst(float2* p, float2 v) { *(FK_GLOBAL v2f*)p = v2f{v.x, v.y}; }
+FK_D void gst(float4* p, float4 v) { *(FK_GLOBAL v4f*)p = v4f{v.x, v.y, v.z, v.w}; }
+FK_D void gst_v2(float2* p, v2f v) { *(FK_GLOBAL v2f*)p = v; }
+
 // ---- synchronisation policies ------------------------------------------------
 struct WorkgroupSync {
     static FK_D void sync() { __syncthreads(); }

@@ -70,15 +70,15 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
         if (k == 0) {
             const float2 z0 = s[G::at(0)];
             const float2 zh = s[G::at(P / 2)];
-            row[0] = float2{(z0.x + z0.y) * scale, (z0.x - z0.y) * scale};   // (DC, Nyquist)
-            row[P / 2] = float2{zh.x * scale, -zh.y * scale};
+            gst(row, float2{(z0.x + z0.y) * scale, (z0.x - z0.y) * scale});   // (DC, Nyquist)
+            gst(row + P / 2, float2{zh.x * scale, -zh.y * scale});
         } else {
             const float2 a = s[G::at(k)], b = s[G::at(P - k)];
             const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
             const float2 o = float2{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
             const float2 t = cmul(o, wsp[c]);
-            row[k] = float2{(e.x + t.x) * scale, (e.y + t.y) * scale};
-            row[P - k] = float2{(e.x - t.x) * scale, -(e.y - t.y) * scale};
+            gst(row + k, float2{(e.x + t.x) * scale, (e.y + t.y) * scale});
+            gst(row + (P - k), float2{(e.x - t.x) * scale, -(e.y - t.y) * scale});
         }
     }
 }
@@ -112,19 +112,19 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
     auto load = [&](int m) -> float2 {
         float2 v;
         if (m < P / 2 && b == 0) {
-            v = tail_rd[m];                               // block preceding this call
+            v = gld(tail_rd + m);                         // block preceding this call
         } else {
             const long long fr = f0 + 2 * m;                 // even: the pair never straddles a block
             if (wide2 && fr + 1 < job.nframes) {             // stereo: one 16-byte load holds both frames
-                const float4 q = *reinterpret_cast<const float4*>(in + fr * 2);
+                const float4 q = gld(reinterpret_cast<const float4*>(in + fr * 2));
                 v = (c == 0) ? float2{q.x, q.z} : float2{q.y, q.w};
             } else if (wide1 && fr + 1 < job.nframes) {      // mono: the pair is contiguous
-                v = *reinterpret_cast<const float2*>(in + fr);
+                v = gld(reinterpret_cast<const float2*>(in + fr));
             } else {
-                v.x = (fr < job.nframes) ? in[fr * cin + c] : 0.0f;
-                v.y = (fr + 1 < job.nframes) ? in[(fr + 1) * cin + c] : 0.0f;
+                v.x = (fr < job.nframes) ? gld(in + fr * cin + c) : 0.0f;
+                v.y = (fr + 1 < job.nframes) ? gld(in + (fr + 1) * cin + c) : 0.0f;
             }
-            if (last && m >= P / 2) tail_wr[m - P / 2] = v;   // becomes the next call's x(n-1)
+            if (last && m >= P / 2) gst(tail_wr + (m - P / 2), v);   // becomes the next call's x(n-1)
         }
         return v;
     };
@@ -191,21 +191,21 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 const int m = h * N2 + tid + c * NT;
-                quad_from_tails(prev[c][h], tail_rd[m], tail_rd[(CIN - 1) * (P / 2) + m]);
+                quad_from_tails(prev[c][h], gld(tail_rd + m), gld(tail_rd + (CIN - 1) * (P / 2) + m));
             }
     } else {
         const Q* __restrict__ src = pcm + (size_t)(b0 - 1) * (P / 2) + tid;
 #pragma unroll
         for (int c = 0; c < COLS; ++c)
 #pragma unroll
-            for (int h = 0; h < H; ++h) prev[c][h] = src[h * N2 + c * NT];
+            for (int h = 0; h < H; ++h) prev[c][h] = gld(src + h * N2 + c * NT);
     }
     {
         const Q* __restrict__ src = pcm + (size_t)b0 * (P / 2) + tid;
 #pragma unroll
         for (int c = 0; c < COLS; ++c)
 #pragma unroll
-            for (int h = 0; h < H; ++h) cur[c][h] = src[h * N2 + c * NT];
+            for (int h = 0; h < H; ++h) cur[c][h] = gld(src + h * N2 + c * NT);
     }
 
 #pragma unroll 1
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
                 for (int h = 0; h < H; ++h) {
                     const int m = h * N2 + tid + c * NT;
 #pragma unroll
-                    for (int ch = 0; ch < CIN; ++ch) tail_wr[ch * (P / 2) + m] = quad_channel(cur[c][h], ch);
+                    for (int ch = 0; ch < CIN; ++ch) gst(tail_wr + ch * (P / 2) + m, quad_channel(cur[c][h], ch));
                 }
         }
 #pragma unroll 1
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
 #pragma unroll
                     for (int c = 0; c < COLS; ++c)
 #pragma unroll
-                        for (int h = 0; h < H; ++h) cur[c][h] = src[h * N2 + c * NT];
+                        for (int h = 0; h < H; ++h) cur[c][h] = gld(src + h * N2 + c * NT);
                 }
             }
             __syncthreads();
@@ -397,12 +397,12 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
             continue;
         }
         if (fr < job.nframes) {
-            out[fr * cout + o] = z.x;
+            gst(out + fr * cout + o, z.x);
             pk_s = fmaxf(pk_s, z.x);
             pk_a = fmaxf(pk_a, fabsf(z.x));
         }
         if (fr + 1 < job.nframes) {
-            out[(fr + 1) * cout + o] = z.y;
+            gst(out + (fr + 1) * cout + o, z.y);
             pk_s = fmaxf(pk_s, z.y);
             pk_a = fmaxf(pk_a, fabsf(z.y));
         }
@@ -531,29 +531,29 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
                 if constexpr (COUT == 2) {
                     const float2 l = zl[c];
                     if (whole) {
-                        *reinterpret_cast<float4*>(out + fr * 2) = float4{l.x, z.x, l.y, z.y};
+                        gst(reinterpret_cast<float4*>(out + fr * 2), float4{l.x, z.x, l.y, z.y});
                         pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
                         pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
                     } else {
                         if (fr < job.nframes) {
-                            out[fr * 2] = l.x; out[fr * 2 + 1] = z.x;
+                            gst(out + fr * 2, l.x); gst(out + fr * 2 + 1, z.x);
                             pk_s = fmaxf(pk_s, fmaxf(l.x, z.x));
                             pk_a = fmaxf(pk_a, fmaxf(fabsf(l.x), fabsf(z.x)));
                         }
                         if (fr + 1 < job.nframes) {
-                            out[fr * 2 + 2] = l.y; out[fr * 2 + 3] = z.y;
+                            gst(out + fr * 2 + 2, l.y); gst(out + fr * 2 + 3, z.y);
                             pk_s = fmaxf(pk_s, fmaxf(l.y, z.y));
                             pk_a = fmaxf(pk_a, fmaxf(fabsf(l.y), fabsf(z.y)));
                         }
                     }
                 } else {
                     if (whole) {
-                        *reinterpret_cast<float2*>(out + fr) = z;
+                        gst(reinterpret_cast<float2*>(out + fr), z);
                         pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
                         pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
                     } else {
-                        if (fr < job.nframes) { out[fr] = z.x; pk_s = fmaxf(pk_s, z.x); pk_a = fmaxf(pk_a, fabsf(z.x)); }
-                        if (fr + 1 < job.nframes) { out[fr + 1] = z.y; pk_s = fmaxf(pk_s, z.y); pk_a = fmaxf(pk_a, fabsf(z.y)); }
+                        if (fr < job.nframes) { gst(out + fr, z.x); pk_s = fmaxf(pk_s, z.x); pk_a = fmaxf(pk_a, fabsf(z.x)); }
+                        if (fr + 1 < job.nframes) { gst(out + fr + 1, z.y); pk_s = fmaxf(pk_s, z.y); pk_a = fmaxf(pk_a, fabsf(z.y)); }
                     }
                 }
             }
@@ -591,7 +591,7 @@ __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const Filt
             const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
             if (!on) continue;
             const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
-            const float2 x = X[(size_t)slot * P];
+            const float2 x = gld(X + (size_t)slot * P);
             const float2 h = Hd[(size_t)j * P];
             re = fmaf(x.x, h.x, re);
             im = fmaf(x.y, h.y, im);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void mac_kernel(const StreamJob* __restrict__ 
         for (int u = 0; u < K - 1 + TT; ++u) {
             const int rel = t0 - (K - 1) + u;             // input block, relative to the call's first
             const int slot = ring_slot(job.slot0, rel, ring);
-            const float4 x = X[(size_t)slot * P2];
+            const float4 x = gld(X + (size_t)slot * P2);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 const int j = tt + K - 1 - u;
@@ -669,20 +669,32 @@ __global__ __launch_bounds__(256) void mac_kernel(const StreamJob* __restrict__ 
 // unrolled by TT — no register moves, no re-loads of H.
 //   HBM bytes per output block and bin: 8*(K+TT)/TT (X) + 8 (Y) + H via L2.
 // ---------------------------------------------------------------------------
+// One bin per thread uses the native 2-float vector (a 64-bit VGPR pair) so that a complex
+// multiply-accumulate is exactly two v_pk_fma_f32: the op_sel / neg_lo modifiers broadcast
+// x.re / x.im, swap h and negate in the instruction itself.  (hipcc's own lowering of the
+// scalar form spends two more VALU per MAC building the (-x.im, x.im) and (h.im, h.re) pairs.)
 template <int NB> struct BinVec;
-template <> struct BinVec<1> { using type = float2; };
+template <> struct BinVec<1> { using type = v2f; };
 template <> struct BinVec<2> { using type = float4; };
 
-__device__ __forceinline__ void cmacv(float2& acc, const float2& x, const float2& h) {
-    acc.x = fmaf(x.x, h.x, acc.x); acc.x = fmaf(-x.y, h.y, acc.x);
-    acc.y = fmaf(x.x, h.y, acc.y); acc.y = fmaf(x.y, h.x, acc.y);
+__device__ __forceinline__ void cmacv(v2f& acc, const v2f& x, const v2f& h) {
+    // acc.lo += x.lo*h.lo ; acc.hi += x.lo*h.hi
+    // acc.lo -= x.hi*h.hi ; acc.hi += x.hi*h.lo
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(acc)
+        : "v"(x), "v"(h));
 }
 __device__ __forceinline__ void cmacv(float4& acc, const float4& x, const float4& h) { cmac2(acc, x, h); }
-__device__ __forceinline__ void vzero(float2& v) { v = float2{0.f, 0.f}; }
+__device__ __forceinline__ void vzero(v2f& v) { v = v2f{0.f, 0.f}; }
 __device__ __forceinline__ void vzero(float4& v) { v = float4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ v2f vload(const v2f* p) { return *(const FK_GLOBAL v2f*)p; }
+__device__ __forceinline__ float4 vload(const float4* p) { return gld(p); }
 
+// Tiles with <= 32 accumulator/window floats per array are held to 128 VGPRs (four waves per
+// SIMD): the streamed loads need that much parallelism in flight.
 template <int TT, int NB, int D>
-__global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+__global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
                                                         float2* __restrict__ Y, int tiles) {
     using V = typename BinVec<NB>::type;
     const StreamJob job = jobs[blockIdx.z];
@@ -705,7 +717,7 @@ __global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restr
         const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
         V xw[TT];                                           // slot q holds X(t0 + q') with q' == q (mod TT)
 #pragma unroll
-        for (int q = 0; q < TT; ++q) xw[q] = X[(size_t)ring_slot(job.slot0, t0 + q, ring) * PV];
+        for (int q = 0; q < TT; ++q) xw[q] = vload(X + (size_t)ring_slot(job.slot0, t0 + q, ring) * PV);
         // software pipeline, D steps deep: the H and X elements of step j+D are
         // requested at step j (keeps >= 40 KB per CU in flight at 2-4 waves/SIMD)
         static_assert(TT % D == 0, "prefetch ring must divide the unroll");
@@ -717,8 +729,8 @@ __global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restr
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (d < K) {
-                hq[d] = *hp;
-                xq[d] = X[(size_t)xs * PV];
+                hq[d] = vload(hp);
+                xq[d] = vload(X + (size_t)xs * PV);
                 hp += PV;
                 xs = (xs == 0) ? ring - 1 : xs - 1;
             }
@@ -731,8 +743,8 @@ __global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restr
                     const V h = hq[jj % D];
                     const V xnew = xq[jj % D];
                     if (j + D < K) {
-                        hq[jj % D] = *hp;
-                        xq[jj % D] = X[(size_t)xs * PV];
+                        hq[jj % D] = vload(hp);
+                        xq[jj % D] = vload(X + (size_t)xs * PV);
                         hp += PV;
                         xs = (xs == 0) ? ring - 1 : xs - 1;
                     }
@@ -755,7 +767,7 @@ __global__ __launch_bounds__(256) void mac_slide_kernel(const StreamJob* __restr
                 if (bv == 0) row[1] = float2{acc[tt].z, acc[tt].w};   // bin 0 is packed: written below
                 else reinterpret_cast<float4*>(row)[bv] = acc[tt];
             } else {
-                if (bv != 0) row[bv] = acc[tt];
+                if (bv != 0) gst_v2(row + bv, acc[tt]);
             }
         }
     }
