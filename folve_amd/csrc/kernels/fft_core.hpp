@@ -273,17 +273,33 @@ struct WaveGeom {
     static constexpr int TWB = make_plan(LOG2N2).total;         // stage B pass tables
 };
 
-// Stage A for one column n2 whose N1 inputs z[n1*N2 + n2] are in v.
-//   twa[(row)*N2 + n2], row 0,1,2 <-> k1 = 1,2,4: exp(-2*pi*i*n2*k1/P)
-template <int LOG2P, bool INV>
-FK_D void stage_a_column(float2* s, const float2* __restrict__ twa, int n2, float2 (&v)[WaveGeom<LOG2P>::N1]) {
+// Stage-A twiddles of one column: the rows k1 = 1, 2, 4 of the table, enough to form
+// W^(n2*k1) for every k1 < 8.  They depend only on the column, so a kernel that transforms
+// many blocks loads them once (StageATw) and keeps them in registers.
+template <int LOG2P>
+struct StageATw {
+    float2 w[3];
+};
+template <int LOG2P>
+FK_D StageATw<LOG2P> load_stage_a_tw(const float2* __restrict__ twa, int n2) {
     using G = WaveGeom<LOG2P>;
-    constexpr int N1 = G::N1, N2 = G::N2;
+    StageATw<LOG2P> t;
+#pragma unroll
+    for (int r = 1, row = 0; row < 3; r *= 2, ++row) t.w[row] = (r < G::N1) ? twa[row * G::N2 + n2] : float2{1.f, 0.f};
+    return t;
+}
+
+// Stage A for one column n2 whose N1 inputs z[n1*N2 + n2] are in v.
+//   tw: rows 0,1,2 <-> k1 = 1,2,4 of exp(-2*pi*i*n2*k1/P)
+template <int LOG2P, bool INV>
+FK_D void stage_a_column(float2* s, const StageATw<LOG2P>& tw, int n2, float2 (&v)[WaveGeom<LOG2P>::N1]) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int N1 = G::N1;
     if constexpr (N1 > 1) {
         dft<N1, INV>(v);
         float2 w[N1];
 #pragma unroll
-        for (int r = 1, row = 0; r < N1; r *= 2, ++row) w[r] = twa[row * N2 + n2];
+        for (int r = 1, row = 0; r < N1; r *= 2, ++row) w[r] = tw.w[row];
 #pragma unroll
         for (int r = 3; r < N1; ++r) {
             if ((r & (r - 1)) != 0) {
@@ -297,6 +313,11 @@ FK_D void stage_a_column(float2* s, const float2* __restrict__ twa, int n2, floa
     }
 #pragma unroll
     for (int k1 = 0; k1 < N1; ++k1) s[k1 * G::RS + phys(n2)] = v[k1];
+}
+template <int LOG2P, bool INV>
+FK_D void stage_a_column(float2* s, const float2* __restrict__ twa, int n2, float2 (&v)[WaveGeom<LOG2P>::N1]) {
+    const StageATw<LOG2P> tw = load_stage_a_tw<LOG2P>(twa, n2);
+    stage_a_column<LOG2P, INV>(s, tw, n2, v);
 }
 
 // Stage A for the columns this thread owns (n2 = tid + c*NT).  src(i) -> z[i].

@@ -172,7 +172,16 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS, H = N1 / 2;
     static_assert(N1 >= 2 && N2 % NT == 0, "walker needs P >= 2048");
-    __shared__ float2 s[G::LDS_ELEMS];
+    // LDS: the FFT image, then the loop-invariant tables (stage-B pass tables, split twiddles).
+    // One workgroup fits per CU anyway (registers), so the spare LDS is free; with the tables
+    // there the loop waits on vmcnt only for the prefetched PCM — vmcnt returns in order, so a
+    // table load inside the loop would also wait for the prefetch and the previous row stores.
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB + P / 2];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    float2* const tws_l = twb_l + G::TWB;
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    for (int i = threadIdx.x; i < P / 2; i += NT) tws_l[i] = f.tw[i];
+    __syncthreads();
     const StreamJob job = jobs[blockIdx.z];
     const int whole = (int)min((long long)job.nblocks, job.nframes / P);
     const int b0 = blockIdx.x * run;
@@ -182,6 +191,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
     const Q* __restrict__ pcm = reinterpret_cast<const Q*>(job.in);     // quad p = frames 2p, 2p+1
     const float2* __restrict__ tail_rd = reinterpret_cast<const float2*>(job.tail_rd);
     float2* __restrict__ tail_wr = reinterpret_cast<float2*>(job.tail_wr);
+
+    // The stage-A twiddles depend only on the thread's columns: loaded once, kept in registers.
+    StageATw<LOG2P> atw[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) atw[c] = load_stage_a_tw<LOG2P>(f.twa, tid + c * NT);
 
     // A block is P/2 quads = H rows of N2; this thread's quads of a block are (h, tid + c*NT).
     Q prev[COLS][H], cur[COLS][H];
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
                     v[h] = quad_channel(prev[c][h], ch);
                     v[H + h] = quad_channel(cur[c][h], ch);
                 }
-                stage_a_column<LOG2P, false>(s, f.twa, t + c * NT, v);
+                stage_a_column<LOG2P, false>(s, atw[c], t + c * NT, v);
             }
             if (ch == CIN - 1) {
                 // the quads are consumed: x(n) becomes x(n-1), and block n+1 starts to load now
@@ -253,10 +267,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
                 }
             }
             __syncthreads();
-            stage_b<LOG2P, false>(s, f.twb, t);
-            float2 wsp[SplitGeom<LOG2P>::CNT];
-            split_prefetch<LOG2P>(wsp, f.tw, t);
+            stage_b<LOG2P, false>(s, twb_l, t);
             __syncthreads();
+            float2 wsp[SplitGeom<LOG2P>::CNT];
+            split_prefetch<LOG2P>(wsp, tws_l, t);             // from LDS
             float2* row = job.fdl + ((size_t)ch * job.ring + slot) * P;
             split_and_store<LOG2P>(s, wsp, t, row, 1.0f);
             __syncthreads();                                  // the image is rewritten by the next stage A
@@ -440,7 +454,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
     static_assert(N1 >= 2 && NT == N2 / 2, "walker needs P = 8192 (one column pair per thread)");
     constexpr int OUTS = (P / 2) / NT;                        // output complex samples per thread (8)
-    __shared__ float2 s[G::LDS_ELEMS];
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];               // image + stage-B pass tables (see forward_walker_kernel)
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    __syncthreads();
     const StreamJob job = jobs[blockIdx.z];
     const int b0 = blockIdx.x * run;
     if (b0 >= job.nblocks) return;
@@ -453,6 +470,8 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     float2 wa[N1];                                            // e^(-i*pi*k/P), k = n1*N2 + ca
 #pragma unroll
     for (int n1 = 0; n1 < N1; ++n1) wa[n1] = tw[n1 * N2 + ca];
+    const StageATw<LOG2P> atw_a = load_stage_a_tw<LOG2P>(f.twa, ca);   // loop-invariant: see forward_walker_kernel
+    const StageATw<LOG2P> atw_b = load_stage_a_tw<LOG2P>(f.twa, cb);
 
     const int nunits = (b1 - b0) * COUT;                      // unit u = (block, channel), channel fastest
     auto row_of = [&](int u) {
@@ -511,10 +530,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
 #pragma unroll
             for (int n1 = 0; n1 < N1; ++n1) { ya[n1] = y[n1 * N2 + ca]; yb[n1] = y[n1 * N2 + cb]; }
         }
-        stage_a_column<LOG2P, true>(s, f.twa, t, za);
-        stage_a_column<LOG2P, true>(s, f.twa, (t == 0) ? N2 / 2 : N2 - t, zb);
+        stage_a_column<LOG2P, true>(s, atw_a, t, za);
+        stage_a_column<LOG2P, true>(s, atw_b, (t == 0) ? N2 / 2 : N2 - t, zb);
         __syncthreads();
-        stage_b<LOG2P, true>(s, f.twb, t);
+        stage_b<LOG2P, true>(s, twb_l, t);
         __syncthreads();
         // ---- transposed read: consecutive lanes take consecutive output frames ----
         const long long fb = (long long)b * P;
