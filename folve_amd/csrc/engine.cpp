@@ -47,6 +47,8 @@ constexpr int kJobSlots = 8;
 
 }  // namespace
 
+struct TableOffsets { int o[4]; int total; };
+
 struct fe_engine {
     std::atomic<int> refs{1};     // creator + one per live filter (streams hold their filter)
     int device = 0;
@@ -54,7 +56,7 @@ struct fe_engine {
     bool own_stream = false;
     std::mutex mu;
     std::map<int, float2*> tw;              // log2P -> [exp(-2 pi i k / 2P), k < 2P | stage A | stage B tables]
-    std::map<int, std::pair<int, int>> tw_off;
+    std::map<int, TableOffsets> tw_off;
     // Lanes: lane 0 is the engine's stream; lane 1 is a second HIP stream that a large
     // batch forks half of its streams onto, so that one half's bandwidth-bound MAC runs
     // beside the other half's latency-bound FFTs (fork/join with events per batch call).
@@ -103,7 +105,7 @@ struct fe_filter {
     // device side (after commit)
     int ndata = 0;
     float2* H = nullptr;
-    uint32_t* mask_dev = nullptr;
+    uint64_t* mask_dev = nullptr;
     fk::PathEntry* paths_dev = nullptr;
     int* out_first_dev = nullptr;
     fk::FilterDev dev{};
@@ -115,11 +117,9 @@ struct fe_stream {
     int max_blocks = 1, ring = 1;
     float2* fdl = nullptr;
     size_t fdl_bytes = 0;
-    float* tails = nullptr;        // [2][cin][P]
     unsigned int* peaks = nullptr; // [2]
     long long blocks_done = 0;
     int slot0 = 0;
-    int parity = 0;
 };
 
 namespace {
@@ -136,19 +136,23 @@ int get_twiddles(fe_engine* e, int log2P, fk::FftTables* out) {
         const int n = fk::fft_table_count(log2P);
         if (n <= 0) return fail(FE_ERR_PARAM, "unsupported block size 2^%d", log2P);
         std::vector<float2> host((size_t)n);
-        int off_a = 0, off_b = 0;
-        fk::fill_fft_tables(log2P, host.data(), &off_a, &off_b);
+        TableOffsets off{};
+        fk::fill_fft_tables(log2P, host.data(), off.o);
+        off.total = n;
         float2* dev = nullptr;
         HIP_TRY(hipMalloc(&dev, sizeof(float2) * host.size()));
         HIP_TRY(hipMemcpy(dev, host.data(), sizeof(float2) * host.size(), hipMemcpyHostToDevice));
         e->tw[log2P] = dev;
-        e->tw_off[log2P] = std::make_pair(off_a, off_b);
+        e->tw_off[log2P] = off;
         it = e->tw.find(log2P);
     }
-    const std::pair<int, int> off = e->tw_off[log2P];
+    const TableOffsets off = e->tw_off[log2P];
     out->tw = it->second;
-    out->twa = it->second + off.first;
-    out->twb = it->second + off.second;
+    out->twa = it->second + off.o[0];
+    out->twb = it->second + off.o[1];
+    const bool has2 = off.o[2] < off.total;           // the 2P-point (stereo) geometry exists for P >= 512
+    out->twa2 = has2 ? it->second + off.o[2] : nullptr;
+    out->twb2 = has2 ? it->second + off.o[3] : nullptr;
     return FE_OK;
 }
 
@@ -182,7 +186,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     std::vector<fk::StreamJob> jobs;
     jobs.reserve(items.size());
     int yunits = 0, max_blocks = 0;
-    bool walker_ok = true, walker_out_ok = true, any_partial = false;
+    bool in_pairs_ok = true, out_pairs_ok = true;
     for (Item& it : items) {
         if (it.left <= 0) continue;
         fe_stream* s = it.s;
@@ -192,14 +196,10 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         j.in = it.in;
         j.out = it.out;
         j.fdl = s->fdl;
-        const size_t tail_elems = (size_t)f->ninp * P;
-        j.tail_rd = s->tails + (size_t)s->parity * tail_elems;
-        j.tail_wr = s->tails + (size_t)(s->parity ^ 1) * tail_elems;
         j.peaks = s->peaks;
         j.nframes = take;
-        if (reinterpret_cast<uintptr_t>(it.in) & 15) walker_ok = false;
-        if (reinterpret_cast<uintptr_t>(it.out) & 15) walker_out_ok = false;
-        if (take % P) any_partial = true;
+        if (reinterpret_cast<uintptr_t>(it.in) & 15) in_pairs_ok = false;
+        if (reinterpret_cast<uintptr_t>(it.out) & 15) out_pairs_ok = false;
         j.nblocks = (int)((take + P - 1) / P);
         j.slot0 = s->slot0;
         j.yunit0 = yunits;
@@ -209,7 +209,6 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         jobs.push_back(j);
         // advance host-side state now: everything below is stream-ordered
         s->slot0 = (s->slot0 + j.nblocks) % s->ring;
-        s->parity ^= 1;
         s->blocks_done += j.nblocks;
         it.in += (size_t)take * f->ninp;
         it.out += (size_t)take * f->nout;
@@ -248,12 +247,12 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     const bool prof = e->profiling;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     if (stagger == 2) HIP_TRY(hipStreamWaitEvent(st, e->stagger_ev, 0));
-    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, walker_ok, any_partial, st));
+    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, st));
     if (stagger == 1) HIP_TRY(hipEventRecord(e->stagger_ev, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
     HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, lane.Y, max_blocks, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
-    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, lane.Y, walker_out_ok, st));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, lane.Y, out_pairs_ok, st));
     if (prof) {
         HIP_TRY(hipEventRecord(e->pev[3], st));
         HIP_TRY(hipEventSynchronize(e->pev[3]));
@@ -551,28 +550,39 @@ int fe_filter_commit(fe_filter* f) {
         HIP_TRY(hipMemcpy(f->paths_dev, entries.data(), entries.size() * sizeof(fk::PathEntry), hipMemcpyHostToDevice));
     }
     if (f->ndata > 0) {
-        const size_t per = (size_t)K * P;
-        std::vector<uint32_t> masks((size_t)f->ndata * 4);
+        const size_t per = (size_t)K * P;              // taps / H per data path
+        const size_t gper = (size_t)(K + 1) * P;       // G rows per data path
+        // populated rows of G(j) = s*H(j) + H(j-1): wherever H(j) or H(j-1) is populated
+        std::vector<uint64_t> masks((size_t)f->ndata * 4, 0);
         float* taps_dev = nullptr;
+        float2* h_tmp = nullptr;
         HIP_TRY(hipMalloc((void**)&taps_dev, per * f->ndata * sizeof(float)));
         for (int d = 0; d < f->ndata; ++d) {
             const PathHost& p = f->paths[(size_t)owners[(size_t)d]];
-            memcpy(&masks[(size_t)d * 4], p.mask, sizeof(p.mask));
+            for (int j = 0; j <= K; ++j) {
+                const bool hj = j < K && ((p.mask[j >> 5] >> (j & 31)) & 1u);
+                const bool hp = j >= 1 && ((p.mask[(j - 1) >> 5] >> ((j - 1) & 31)) & 1u);
+                if (hj || hp) masks[(size_t)d * 4 + (size_t)(j >> 6)] |= 1ull << (j & 63);
+            }
             hipError_t r = hipMemcpy(taps_dev + per * d, p.taps.data(), per * sizeof(float), hipMemcpyHostToDevice);
             if (r != hipSuccess) { (void)hipFree(taps_dev); return fail(FE_ERR_DEVICE, "tap upload: %s", hipGetErrorString(r)); }
         }
-        HIP_TRY(hipMalloc((void**)&f->H, per * f->ndata * sizeof(float2)));
-        HIP_TRY(hipMalloc((void**)&f->mask_dev, masks.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(f->mask_dev, masks.data(), masks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(fk::launch_filter_transform(taps_dev, f->H, f->ndata, K, f->log2P, tabs, e->stream));
+        HIP_TRY(hipMalloc((void**)&h_tmp, per * f->ndata * sizeof(float2)));
+        HIP_TRY(hipMalloc((void**)&f->H, gper * f->ndata * sizeof(float2)));
+        HIP_TRY(hipMalloc((void**)&f->mask_dev, masks.size() * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(f->mask_dev, masks.data(), masks.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(fk::launch_filter_transform(taps_dev, h_tmp, f->H, f->ndata, K, f->log2P, tabs, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         HIP_TRY(hipFree(taps_dev));
+        HIP_TRY(hipFree(h_tmp));
     }
-    f->dev.cin = f->ninp; f->dev.cout = f->nout; f->dev.P = P; f->dev.log2P = f->log2P; f->dev.K = K;
+    f->dev.cin = f->ninp; f->dev.cout = f->nout; f->dev.P = P; f->dev.log2P = f->log2P; f->dev.K = K + 1;   // rows of G
     f->dev.H = f->H; f->dev.mask = f->mask_dev; f->dev.paths = f->paths_dev; f->dev.out_first = f->out_first_dev;
     f->dev.tw = tabs.tw;
     f->dev.twa = tabs.twa;
     f->dev.twb = tabs.twb;
+    f->dev.twa2 = tabs.twa2;
+    f->dev.twb2 = tabs.twb2;
     f->committed = true;
     return FE_OK;
 }
@@ -637,18 +647,14 @@ int fe_stream_open(fe_filter* f, int max_blocks_per_call, fe_stream** out) {
     if (!s) return fail(FE_ERR_ALLOC, "out of memory");
     s->f = f; s->eng = e;
     s->max_blocks = max_blocks_per_call;
-    s->ring = f->K - 1 + max_blocks_per_call;
+    s->ring = f->K + max_blocks_per_call;           // K + 1 rows of G reach K blocks back
     s->fdl_bytes = (size_t)f->ninp * s->ring * f->P * sizeof(float2);
-    const size_t tail_bytes = (size_t)2 * f->ninp * f->P * sizeof(float);
     hipError_t r = hipMalloc((void**)&s->fdl, s->fdl_bytes);
-    if (r == hipSuccess) r = hipMalloc((void**)&s->tails, tail_bytes);
     if (r == hipSuccess) r = hipMalloc((void**)&s->peaks, 2 * sizeof(unsigned int));
     if (r == hipSuccess) r = hipMemsetAsync(s->fdl, 0, s->fdl_bytes, e->stream);
-    if (r == hipSuccess) r = hipMemsetAsync(s->tails, 0, tail_bytes, e->stream);
     if (r == hipSuccess) r = hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream);
     if (r != hipSuccess) {
         if (s->fdl) (void)hipFree(s->fdl);
-        if (s->tails) (void)hipFree(s->tails);
         if (s->peaks) (void)hipFree(s->peaks);
         delete s;
         return fail(r == hipErrorOutOfMemory ? FE_ERR_ALLOC : FE_ERR_DEVICE, "stream allocation: %s", hipGetErrorString(r));
@@ -664,10 +670,8 @@ int fe_stream_reset(fe_stream* s) {
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemsetAsync(s->fdl, 0, s->fdl_bytes, e->stream));
-    HIP_TRY(hipMemsetAsync(s->tails, 0, (size_t)2 * s->f->ninp * s->f->P * sizeof(float), e->stream));
     HIP_TRY(hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream));
     s->slot0 = 0;
-    s->parity = 0;
     s->blocks_done = 0;
     return FE_OK;
 }
@@ -680,7 +684,6 @@ void fe_stream_close(fe_stream* s) {
         (void)hipSetDevice(e->device);
         (void)hipStreamSynchronize(e->stream);
         (void)hipFree(s->fdl);
-        (void)hipFree(s->tails);
         (void)hipFree(s->peaks);
     }
     fe_filter_release(s->f);

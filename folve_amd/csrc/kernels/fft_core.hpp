@@ -259,38 +259,40 @@ struct WaveGeom {
     static constexpr int NT = threads_for(P);
     static constexpr int N1 = (P >= 1024) ? P / 1024 : 1;      // == waves per workgroup
     static constexpr int N2 = P / N1;
-    static constexpr int LOG2N2 = LOG2P - (N1 == 8 ? 3 : N1 == 4 ? 2 : N1 == 2 ? 1 : 0);
+    static constexpr int LOG2N2 = LOG2P - (N1 == 16 ? 4 : N1 == 8 ? 3 : N1 == 4 ? 2 : N1 == 2 ? 1 : 0);
     // Row stride: the padded row plus 32/N1 so that a transposed read (lanes along
     // k = k1 + N1*k2) touches 32 distinct 8-byte banks.
     static constexpr int RS = lds_elems(N2) + (N1 > 1 ? 32 / N1 : 0);
     static constexpr int LDS_ELEMS = N1 * RS;
     static constexpr int COLS = (N2 + NT - 1) / NT;             // stage-A columns per thread
     static_assert(NT == 64 * N1 || N1 == 1, "one wavefront per row");
+    static_assert(N1 <= 16, "radix of stage A");
     // element Z[k] after stage B
     static FK_HD int at(int k) { return (k % N1) * RS + phys(k / N1); }
     // twiddle buffers (host fills them: kernels.hip fill_fft_tables)
-    static constexpr int TWA = (N1 > 1) ? 3 * N2 : 0;           // stage A rows k1 = 1, 2, 4
+    static constexpr int AROWS = 4;                             // stage A rows k1 = 1, 2, 4, 8
+    static constexpr int TWA = (N1 > 1) ? AROWS * N2 : 0;
     static constexpr int TWB = make_plan(LOG2N2).total;         // stage B pass tables
 };
 
-// Stage-A twiddles of one column: the rows k1 = 1, 2, 4 of the table, enough to form
-// W^(n2*k1) for every k1 < 8.  They depend only on the column, so a kernel that transforms
+// Stage-A twiddles of one column: the rows k1 = 1, 2, 4, 8 of the table, enough to form
+// W^(n2*k1) for every k1 < 16.  They depend only on the column, so a kernel that transforms
 // many blocks loads them once (StageATw) and keeps them in registers.
 template <int LOG2P>
 struct StageATw {
-    float2 w[3];
+    float2 w[4];
 };
 template <int LOG2P>
 FK_D StageATw<LOG2P> load_stage_a_tw(const float2* __restrict__ twa, int n2) {
     using G = WaveGeom<LOG2P>;
     StageATw<LOG2P> t;
 #pragma unroll
-    for (int r = 1, row = 0; row < 3; r *= 2, ++row) t.w[row] = (r < G::N1) ? twa[row * G::N2 + n2] : float2{1.f, 0.f};
+    for (int r = 1, row = 0; row < 4; r *= 2, ++row) t.w[row] = (r < G::N1) ? twa[row * G::N2 + n2] : float2{1.f, 0.f};
     return t;
 }
 
 // Stage A for one column n2 whose N1 inputs z[n1*N2 + n2] are in v.
-//   tw: rows 0,1,2 <-> k1 = 1,2,4 of exp(-2*pi*i*n2*k1/P)
+//   tw: rows 0..3 <-> k1 = 1,2,4,8 of exp(-2*pi*i*n2*k1/N), N = the transform length
 template <int LOG2P, bool INV>
 FK_D void stage_a_column(float2* s, const StageATw<LOG2P>& tw, int n2, float2 (&v)[WaveGeom<LOG2P>::N1]) {
     using G = WaveGeom<LOG2P>;

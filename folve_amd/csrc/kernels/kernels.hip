@@ -4,13 +4,19 @@
 // (/root/reference/sound-processor.cc:98-127) and what `impdata_create` does at
 // filter set-up (/root/reference/zita-config.cc:163): uniformly partitioned FFT
 // convolution, partition = block = P = `fragm` frames, evaluated here as
-// overlap-save so that every block of a call is independent:
-//   K1 forward : window [x(n-1) | x(n)] (2P reals, deinterleaved from PCM) ->
-//                real FFT through a P-point complex FFT in LDS -> FDL ring row
-//   K2 mac     : Y(n) = sum_paths sum_j X(n-j) * H(j), time-tiled in registers
+// overlap-save so that every block of a call is independent.  The overlap-save
+// spectrum X(n) = FFT([x(n-1) | x(n)]) is never formed: with Z(n) = FFT([x(n) | 0]),
+// X(n) = Z(n-1) + s*Z(n), s_k = (-1)^k, hence
+//     Y(n) = sum_j X(n-j) H(j) = sum_{j=0..K} Z(n-j) G(j),  G(j) = s*H(j) + H(j-1),
+// so each PCM block is read and transformed exactly once and a stream carries no
+// time-domain state — only its ring of spectra.
+//   K1 forward : block [x(n) | 0] -> Z(n) -> FDL ring row.  Stereo: ONE 2P-point complex FFT of
+//                z = L + i*R (interleaved PCM loaded as is), spectra separated by symmetry;
+//                otherwise a real FFT through a P-point complex FFT per channel
+//   K2 mac     : Y(n) = sum_paths sum_{j<=K} Z(n-j) * G(j), time-tiled in registers
 //   K3 inverse : Y(n) -> P-point complex IFFT in LDS -> last P samples of the
 //                window, interleaved PCM store, per-stream peak
-//   K0 filter  : taps -> H spectra, 1/(2P) folded in (as zita folds 0.5/parsize)
+//   K0 filter  : taps -> H spectra, 1/(2P) folded in (as zita folds 0.5/parsize), then G
 #include "kernels.h"
 
 #include <math.h>
@@ -29,6 +35,11 @@ __device__ __forceinline__ void cmac2(float4& acc, const float4& x, const float4
     acc.y = fmaf(x.x, h.y, acc.y); acc.y = fmaf(x.y, h.x, acc.y);
     acc.z = fmaf(x.z, h.z, acc.z); acc.z = fmaf(-x.w, h.w, acc.z);
     acc.w = fmaf(x.z, h.w, acc.w); acc.w = fmaf(x.w, h.z, acc.w);
+}
+
+// populated-row bitmap of a data path: K + 1 <= 129 rows of G
+__device__ __forceinline__ bool mask_bit(uint64_t lo, uint64_t hi, uint64_t top, int j) {
+    return ((j < 64 ? lo >> j : j < 128 ? hi >> (j - 64) : top >> (j - 128)) & 1) != 0;
 }
 
 __device__ __forceinline__ int ring_slot(int slot0, int rel, int ring) {
@@ -84,47 +95,39 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
 }
 
 // ---------------------------------------------------------------------------
-// K1, general form: one workgroup per (block, input channel).  grid (max blocks, input channels, streams)
-// Handles everything (any channel count, unaligned PCM, a short last block, P < 2048); the
-// pair-walker below takes the whole blocks of mono / stereo streams when it applies, and this
-// kernel is then launched with first_block = whole blocks, i.e. for a short last block only.
+// K1, general form: one workgroup per (block, input channel): Z(n) = FFT_2P([x(n) | 0]) of one
+// channel through a P-point complex FFT.  grid (max blocks, input channels, streams)
+// Any channel count, unaligned PCM, short last block, any P.
 // ---------------------------------------------------------------------------
 template <int LOG2P>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const StreamJob* __restrict__ jobs,
-                                                                      FilterDev f, int skip_whole) {
+                                                                      FilterDev f) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     __shared__ float2 s[G::LDS_ELEMS];
     const StreamJob job = jobs[blockIdx.z];
-    const int b = blockIdx.x + (skip_whole ? (int)(job.nframes / P) : 0);   // the walker did the whole blocks
+    const int b = blockIdx.x;
     if (b >= job.nblocks) return;
     const int c = blockIdx.y;
     const int tid = threadIdx.x;
     const int cin = f.cin;
-    const long long f0 = (long long)(b - 1) * P;          // frame of window sample 0
-    const bool last = (b == job.nblocks - 1);
+    const long long f0 = (long long)b * P;               // first frame of the block
     const float* __restrict__ in = job.in;
-    const float2* __restrict__ tail_rd = reinterpret_cast<const float2*>(job.tail_rd + (size_t)c * P);
-    float2* __restrict__ tail_wr = reinterpret_cast<float2*>(job.tail_wr + (size_t)c * P);
     const bool wide2 = (cin == 2) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
     const bool wide1 = (cin == 1) && ((reinterpret_cast<uintptr_t>(in) & 7) == 0);
 
-    auto load = [&](int m) -> float2 {
+    auto load = [&](int m) -> float2 {                    // z[m] = (x[2m], x[2m+1]); the upper half is zero
+        if (m >= P / 2) return float2{0.0f, 0.0f};
         float2 v;
-        if (m < P / 2 && b == 0) {
-            v = gld(tail_rd + m);                         // block preceding this call
+        const long long fr = f0 + 2 * m;                  // even: the pair never straddles a block
+        if (wide2 && fr + 1 < job.nframes) {              // stereo: one 16-byte load holds both frames
+            const float4 q = gld(reinterpret_cast<const float4*>(in + fr * 2));
+            v = (c == 0) ? float2{q.x, q.z} : float2{q.y, q.w};
+        } else if (wide1 && fr + 1 < job.nframes) {       // mono: the pair is contiguous
+            v = gld(reinterpret_cast<const float2*>(in + fr));
         } else {
-            const long long fr = f0 + 2 * m;                 // even: the pair never straddles a block
-            if (wide2 && fr + 1 < job.nframes) {             // stereo: one 16-byte load holds both frames
-                const float4 q = gld(reinterpret_cast<const float4*>(in + fr * 2));
-                v = (c == 0) ? float2{q.x, q.z} : float2{q.y, q.w};
-            } else if (wide1 && fr + 1 < job.nframes) {      // mono: the pair is contiguous
-                v = gld(reinterpret_cast<const float2*>(in + fr));
-            } else {
-                v.x = (fr < job.nframes) ? gld(in + fr * cin + c) : 0.0f;
-                v.y = (fr + 1 < job.nframes) ? gld(in + (fr + 1) * cin + c) : 0.0f;
-            }
-            if (last && m >= P / 2) gst(tail_wr + (m - P / 2), v);   // becomes the next call's x(n-1)
+            v.x = (fr < job.nframes) ? gld(in + fr * cin + c) : 0.0f;
+            v.y = (fr + 1 < job.nframes) ? gld(in + (fr + 1) * cin + c) : 0.0f;
         }
         return v;
     };
@@ -140,140 +143,65 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
 }
 
 // ---------------------------------------------------------------------------
-// K1, fast form ("pair-walker"): whole blocks of mono / stereo PCM, P >= 2048.
-// grid (runs of `run` consecutive blocks, 1, streams)
-//
-// One workgroup owns the stream's channel pair and walks `run` consecutive blocks.
-// A block's interleaved PCM is loaded ONCE, as raw quads (L[2m], R[2m], L[2m+1],
-// R[2m+1]) — plain 16-byte loads — and feeds both channels' FFTs; the quads of block
-// n stay in registers as the x(n-1) half of block n+1's overlap-save window; the
-// loads of block n+1 are issued as soon as the second channel's stage A has consumed
-// the registers, so they fly during its stage B, split and stores.  Every PCM byte is
-// requested once (the general kernel asks for each byte four times: two windows x
-// two channels, and concurrent workgroups do not share through L2).
+// K1, stereo form: ONE 2P-point complex FFT of z[t] = L[t] + i*R[t] (t < P, zero above) per block.
+// grid (max blocks, 1, streams), P/8 threads (1024 at P = 8192: 16 wavefronts, one per LDS row).
+// Interleaved stereo PCM *is* z: frames are loaded as plain (L, R) pairs, no deinterleave and no
+// over-fetch; half of stage A's inputs are zero; the two real spectra come out of the symmetry
+//     ZL[k] = (Z[k] + conj Z[2P-k]) / 2,   ZR[k] = (Z[k] - conj Z[2P-k]) / (2i).
 // ---------------------------------------------------------------------------
-template <int CIN> struct PcmQuad;
-template <> struct PcmQuad<1> { using type = float2; };     // (x[2m], x[2m+1])
-template <> struct PcmQuad<2> { using type = float4; };     // (L[2m], R[2m], L[2m+1], R[2m+1])
-__device__ __forceinline__ float2 quad_channel(const float2& q, int) { return q; }
-__device__ __forceinline__ float2 quad_channel(const float4& q, int ch) {
-    return ch == 0 ? float2{q.x, q.z} : float2{q.y, q.w};
-}
-__device__ __forceinline__ void quad_from_tails(float2& q, const float2& t0, const float2&) { q = t0; }
-__device__ __forceinline__ void quad_from_tails(float4& q, const float2& t0, const float2& t1) {
-    q = float4{t0.x, t1.x, t0.y, t1.y};
-}
-
-template <int LOG2P, int CIN>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
-                                                                             FilterDev f, int run) {
-    using G = WaveGeom<LOG2P>;
-    using Q = typename PcmQuad<CIN>::type;
-    constexpr int P = 1 << LOG2P;
-    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS, H = N1 / 2;
-    static_assert(N1 >= 2 && N2 % NT == 0, "walker needs P >= 2048");
-    // LDS: the FFT image, then the loop-invariant tables (stage-B pass tables, split twiddles).
-    // One workgroup fits per CU anyway (registers), so the spare LDS is free; with the tables
-    // there the loop waits on vmcnt only for the prefetched PCM — vmcnt returns in order, so a
-    // table load inside the loop would also wait for the prefetch and the previous row stores.
-    __shared__ float2 s[G::LDS_ELEMS + G::TWB + P / 2];
-    float2* const twb_l = s + G::LDS_ELEMS;
-    float2* const tws_l = twb_l + G::TWB;
-    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
-    for (int i = threadIdx.x; i < P / 2; i += NT) tws_l[i] = f.tw[i];
-    __syncthreads();
+template <int LOG2P>
+__global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(const StreamJob* __restrict__ jobs,
+                                                                               FilterDev f) {
+    using G = WaveGeom<LOG2P + 1>;                        // geometry of the 2P-point transform
+    constexpr int P = 1 << LOG2P, N = 2 * P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
+    constexpr bool GUARD = (N2 % NT) != 0;
+    __shared__ float2 s[G::LDS_ELEMS];
     const StreamJob job = jobs[blockIdx.z];
-    const int whole = (int)min((long long)job.nblocks, job.nframes / P);
-    const int b0 = blockIdx.x * run;
-    if (b0 >= whole) return;
-    const int b1 = min(b0 + run, whole);
+    const int b = blockIdx.x;
+    if (b >= job.nblocks) return;
     const int tid = threadIdx.x;
-    const Q* __restrict__ pcm = reinterpret_cast<const Q*>(job.in);     // quad p = frames 2p, 2p+1
-    const float2* __restrict__ tail_rd = reinterpret_cast<const float2*>(job.tail_rd);
-    float2* __restrict__ tail_wr = reinterpret_cast<float2*>(job.tail_wr);
+    const float2* __restrict__ pcm = reinterpret_cast<const float2*>(job.in) + (size_t)b * P;   // frame t: (L, R)
+    const long long left = job.nframes - (long long)b * P;                                      // valid frames
 
-    // The stage-A twiddles depend only on the thread's columns: loaded once, kept in registers.
-    StageATw<LOG2P> atw[COLS];
+    float2 v[COLS][N1];
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) atw[c] = load_stage_a_tw<LOG2P>(f.twa, tid + c * NT);
-
-    // A block is P/2 quads = H rows of N2; this thread's quads of a block are (h, tid + c*NT).
-    Q prev[COLS][H], cur[COLS][H];
-    if (b0 == 0) {
+    for (int c = 0; c < COLS; ++c) {
+        const int n2 = tid + c * NT;
+        if (GUARD && n2 >= N2) continue;
 #pragma unroll
-        for (int c = 0; c < COLS; ++c)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const int m = h * N2 + tid + c * NT;
-                quad_from_tails(prev[c][h], gld(tail_rd + m), gld(tail_rd + (CIN - 1) * (P / 2) + m));
-            }
-    } else {
-        const Q* __restrict__ src = pcm + (size_t)(b0 - 1) * (P / 2) + tid;
-#pragma unroll
-        for (int c = 0; c < COLS; ++c)
-#pragma unroll
-            for (int h = 0; h < H; ++h) prev[c][h] = gld(src + h * N2 + c * NT);
-    }
-    {
-        const Q* __restrict__ src = pcm + (size_t)b0 * (P / 2) + tid;
-#pragma unroll
-        for (int c = 0; c < COLS; ++c)
-#pragma unroll
-            for (int h = 0; h < H; ++h) cur[c][h] = gld(src + h * N2 + c * NT);
-    }
-
-#pragma unroll 1
-    for (int b = b0; b < b1; ++b) {
-        const int slot = ring_slot(job.slot0, b, job.ring);
-        if (b == job.nblocks - 1) {                           // becomes the next call's x(n-1)
-#pragma unroll
-            for (int c = 0; c < COLS; ++c)
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const int m = h * N2 + tid + c * NT;
-#pragma unroll
-                    for (int ch = 0; ch < CIN; ++ch) gst(tail_wr + ch * (P / 2) + m, quad_channel(cur[c][h], ch));
-                }
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const int t = n1 * N2 + n2;
+            const bool in_block = (N1 >= 2) ? (n1 < N1 / 2) : (t < P);
+            v[c][n1] = (in_block && t < left) ? gld(pcm + t) : float2{0.0f, 0.0f};
         }
-#pragma unroll 1
-        for (int ch = 0; ch < CIN; ++ch) {
-            // Opaque copy of the thread index: keeps the (cheap) LDS / table address arithmetic
-            // of the FFT inside the loop instead of hoisted into ~100 loop-invariant registers.
-            int t = tid;
-            asm volatile("" : "+v"(t));
-            // ---- stage A straight from the register quads ----
+    }
 #pragma unroll
-            for (int c = 0; c < COLS; ++c) {
-                float2 v[N1];
+    for (int c = 0; c < COLS; ++c) {
+        const int n2 = tid + c * NT;
+        if (GUARD && n2 >= N2) continue;
+        stage_a_column<LOG2P + 1, false>(s, f.twa2, n2, v[c]);
+    }
+    __syncthreads();
+    stage_b<LOG2P + 1, false>(s, f.twb2, tid);
+    __syncthreads();
+    const int slot = ring_slot(job.slot0, b, job.ring);
+    float2* __restrict__ rowL = job.fdl + ((size_t)0 * job.ring + slot) * P;
+    float2* __restrict__ rowR = job.fdl + ((size_t)1 * job.ring + slot) * P;
+    constexpr int CNT = (P + NT - 1) / NT;
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    v[h] = quad_channel(prev[c][h], ch);
-                    v[H + h] = quad_channel(cur[c][h], ch);
-                }
-                stage_a_column<LOG2P, false>(s, atw[c], t + c * NT, v);
-            }
-            if (ch == CIN - 1) {
-                // the quads are consumed: x(n) becomes x(n-1), and block n+1 starts to load now
-#pragma unroll
-                for (int c = 0; c < COLS; ++c)
-#pragma unroll
-                    for (int h = 0; h < H; ++h) prev[c][h] = cur[c][h];
-                if (b + 1 < b1) {
-                    const Q* __restrict__ src = pcm + (size_t)(b + 1) * (P / 2) + tid;
-#pragma unroll
-                    for (int c = 0; c < COLS; ++c)
-#pragma unroll
-                        for (int h = 0; h < H; ++h) cur[c][h] = gld(src + h * N2 + c * NT);
-                }
-            }
-            __syncthreads();
-            stage_b<LOG2P, false>(s, twb_l, t);
-            __syncthreads();
-            float2 wsp[SplitGeom<LOG2P>::CNT];
-            split_prefetch<LOG2P>(wsp, tws_l, t);             // from LDS
-            float2* row = job.fdl + ((size_t)ch * job.ring + slot) * P;
-            split_and_store<LOG2P>(s, wsp, t, row, 1.0f);
-            __syncthreads();                                  // the image is rewritten by the next stage A
+    for (int c = 0; c < CNT; ++c) {
+        const int k = tid + c * NT;
+        if (k >= P) continue;
+        const float2 a = s[G::at(k)];
+        if (k == 0) {
+            const float2 ny = s[G::at(P)];
+            gst(rowL, float2{a.x, ny.x});                 // packed (DC, Nyquist)
+            gst(rowR, float2{a.y, ny.y});
+        } else {
+            const float2 bb = s[G::at(N - k)];
+            gst(rowL + k, float2{0.5f * (a.x + bb.x), 0.5f * (a.y - bb.y)});
+            gst(rowR + k, float2{0.5f * (a.y + bb.y), -0.5f * (a.x - bb.x)});
         }
     }
 }
@@ -300,6 +228,23 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void filter_kernel(const float
     split_prefetch<LOG2P>(wsp, tw, tid);
     __syncthreads();
     split_and_store<LOG2P>(s, wsp, tid, H + ((size_t)d * K + j) * P, 0.5f / (float)P);
+}
+
+// G(j) = s*H(j) + H(j-1), j = 0..K (H(-1) = H(K) = 0), s_k = (-1)^k; the packed bin 0 holds
+// (DC, Nyquist) and s = +1 for both (P is even).  grid (K + 1, data paths)
+__global__ __launch_bounds__(256) void make_g_kernel(const float2* __restrict__ H, float2* __restrict__ Gs, int K,
+                                                     int P) {
+    const int j = blockIdx.x, d = blockIdx.y;
+    const float2* __restrict__ h = H + ((size_t)d * K + j) * P;
+    const float2* __restrict__ hp = H + ((size_t)d * K + (j - 1)) * P;
+    float2* __restrict__ g = Gs + ((size_t)d * (K + 1) + j) * P;
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        const float sgn = (k & 1) ? -1.0f : 1.0f;
+        float2 acc{0.0f, 0.0f};
+        if (j < K) { const float2 x = h[k]; acc = float2{sgn * x.x, (k == 0 ? 1.0f : sgn) * x.y}; }
+        if (j >= 1) { const float2 x = hp[k]; acc.x += x.x; acc.y += x.y; }
+        g[k] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -454,7 +399,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
     static_assert(N1 >= 2 && NT == N2 / 2, "walker needs P = 8192 (one column pair per thread)");
     constexpr int OUTS = (P / 2) / NT;                        // output complex samples per thread (8)
-    __shared__ float2 s[G::LDS_ELEMS + G::TWB];               // image + stage-B pass tables (see forward_walker_kernel)
+    // LDS: the FFT image, then the stage-B pass tables.  One workgroup fits per CU anyway
+    // (registers), so the spare LDS is free; with the tables there the loop waits on vmcnt only for
+    // the prefetched Y row — vmcnt returns in order, so a table load inside the loop would also wait
+    // for the prefetch and the previous block's stores.
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     __syncthreads();
@@ -470,7 +419,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     float2 wa[N1];                                            // e^(-i*pi*k/P), k = n1*N2 + ca
 #pragma unroll
     for (int n1 = 0; n1 < N1; ++n1) wa[n1] = tw[n1 * N2 + ca];
-    const StageATw<LOG2P> atw_a = load_stage_a_tw<LOG2P>(f.twa, ca);   // loop-invariant: see forward_walker_kernel
+    const StageATw<LOG2P> atw_a = load_stage_a_tw<LOG2P>(f.twa, ca);   // loop-invariant: kept in registers
     const StageATw<LOG2P> atw_b = load_stage_a_tw<LOG2P>(f.twa, cb);
 
     const int nunits = (b1 - b0) * COUT;                      // unit u = (block, channel), channel fastest
@@ -490,7 +439,9 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
 
 #pragma unroll 1
     for (int u = 0; u < nunits; ++u) {
-        int t = tid;                                          // opaque copy: keeps address arithmetic in the loop
+        // Opaque copy of the thread index: keeps the (cheap) LDS / table address arithmetic of the FFT
+        // inside the loop instead of hoisted into ~100 loop-invariant registers.
+        int t = tid;
         asm volatile("" : "+v"(t));
         const int b = b0 + u / COUT, o = u % COUT;
         // ---- Hermitian fold in registers (see inverse_kernel) ----
@@ -604,10 +555,10 @@ __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const Filt
         const PathEntry pth = f.paths[pe];
         const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
         const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
-        const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
-        const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
+        const uint64_t mlo = f.mask[pth.data * 4 + 0];
+        const uint64_t mhi = f.mask[pth.data * 4 + 1], mtop = f.mask[pth.data * 4 + 2];
         for (int j = g; j < K; j += G) {
-            const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
+            const bool on = mask_bit(mlo, mhi, mtop, j);
             if (!on) continue;
             const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
             const float2 x = gld(X + (size_t)slot * P);
@@ -648,8 +599,8 @@ __global__ __launch_bounds__(256) void mac_kernel(const StreamJob* __restrict__ 
         const PathEntry pth = f.paths[pe];
         const float4* __restrict__ Hd = reinterpret_cast<const float4*>(f.H + (size_t)pth.data * K * P) + bp;
         const float4* __restrict__ X = reinterpret_cast<const float4*>(job.fdl + (size_t)pth.in_ch * ring * P) + bp;
-        const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
-        const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
+        const uint64_t mlo = f.mask[pth.data * 4 + 0];
+        const uint64_t mhi = f.mask[pth.data * 4 + 1], mtop = f.mask[pth.data * 4 + 2];
         for (int u = 0; u < K - 1 + TT; ++u) {
             const int rel = t0 - (K - 1) + u;             // input block, relative to the call's first
             const int slot = ring_slot(job.slot0, rel, ring);
@@ -658,7 +609,7 @@ __global__ __launch_bounds__(256) void mac_kernel(const StreamJob* __restrict__ 
             for (int tt = 0; tt < TT; ++tt) {
                 const int j = tt + K - 1 - u;
                 if (j >= 0 && j < K) {
-                    const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
+                    const bool on = mask_bit(mlo, mhi, mtop, j);
                     if (on) {
                         const float4 h = Hd[(size_t)j * P2];
                         cmac2(acc[tt], x, h);
@@ -732,8 +683,8 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
         const PathEntry pth = f.paths[pe];
         const V* __restrict__ Hd = reinterpret_cast<const V*>(f.H + (size_t)pth.data * K * P) + bv;
         const V* __restrict__ X = reinterpret_cast<const V*>(job.fdl + (size_t)pth.in_ch * ring * P) + bv;
-        const uint64_t mlo = (uint64_t)f.mask[pth.data * 4 + 0] | ((uint64_t)f.mask[pth.data * 4 + 1] << 32);
-        const uint64_t mhi = (uint64_t)f.mask[pth.data * 4 + 2] | ((uint64_t)f.mask[pth.data * 4 + 3] << 32);
+        const uint64_t mlo = f.mask[pth.data * 4 + 0];
+        const uint64_t mhi = f.mask[pth.data * 4 + 1], mtop = f.mask[pth.data * 4 + 2];
         V xw[TT];                                           // slot q holds X(t0 + q') with q' == q (mod TT)
 #pragma unroll
         for (int q = 0; q < TT; ++q) xw[q] = vload(X + (size_t)ring_slot(job.slot0, t0 + q, ring) * PV);
@@ -767,7 +718,7 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
                         hp += PV;
                         xs = (xs == 0) ? ring - 1 : xs - 1;
                     }
-                    const bool on = (j < 64) ? ((mlo >> j) & 1) : ((mhi >> (j - 64)) & 1);
+                    const bool on = mask_bit(mlo, mhi, mtop, j);
                     if (on) {
 #pragma unroll
                         for (int tt = 0; tt < TT; ++tt) cmacv(acc[tt], xw[(tt - jj) & (TT - 1)], h);
@@ -810,40 +761,30 @@ hipError_t dispatch_log2p(int log2P, A&&... a) {
 
 template <int L>
 struct FwdLaunch {
-    // walker_ok: every stream of the launch has 16-byte aligned PCM (host-checked).
-    static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool walker_ok,
-                          bool any_partial, hipStream_t st) {
-        constexpr int NT = WaveGeom<L>::NT;
-        if constexpr (L >= 11) {
-            // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
-            if (walker_ok && (f.cin == 1 || f.cin == 2) && (long long)njobs * max_blocks >= 256) {
-                // Blocks per workgroup: as long a walk as still leaves >= ~2 workgroups per CU.
-                static const char* rl = getenv("FOLVE_AMD_RUNLEN");
-                int runlen = rl ? atoi(rl) : 8;
-                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
-                dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
-                if (f.cin == 2) hipLaunchKernelGGL((forward_walker_kernel<L, 2>), grid, block, 0, st, jobs, f, runlen);
-                else hipLaunchKernelGGL((forward_walker_kernel<L, 1>), grid, block, 0, st, jobs, f, runlen);
-                hipError_t e = hipGetLastError();
-                if (e != hipSuccess || !any_partial) return e;
-                dim3 grid2(1, f.cin, njobs);                  // the short last block of each stream, if any
-                hipLaunchKernelGGL(forward_kernel<L>, grid2, block, 0, st, jobs, f, 1);
+    // pairs_ok: every stream's PCM pointer is 8-byte aligned (stereo frames loaded as float2)
+    static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
+                          hipStream_t st) {
+        if constexpr (L >= 9) {                           // 2P >= 1024: the stereo transform exists
+            if (f.cin == 2 && pairs_ok && f.twa2) {
+                dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
+                hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
                 return hipGetLastError();
             }
         }
-        dim3 grid(max_blocks, f.cin, njobs), block(NT);
-        hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f, 0);
+        dim3 grid(max_blocks, f.cin, njobs), block(WaveGeom<L>::NT);
+        hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f);
         return hipGetLastError();
     }
 };
 template <int L>
 struct InvLaunch {
-    // walker_ok: every stream's output pointer is 16-byte aligned (host-checked).
+    // pairs_ok: every stream's output pointer is 16-byte aligned
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          bool walker_ok, hipStream_t st) {
+                          bool pairs_ok, hipStream_t st) {
         constexpr int NT = WaveGeom<L>::NT;
         if constexpr (L == 13) {      // P = 8192 (every filter longer than 4096 taps): one column pair per thread
-            if (walker_ok && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
+            // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
+            if (pairs_ok && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
                 static const char* rl = getenv("FOLVE_AMD_RUNLEN");
                 int runlen = rl ? atoi(rl) : 8;
                 while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
@@ -860,18 +801,23 @@ struct InvLaunch {
 };
 template <int L>
 struct FilterLaunch {
-    static hipError_t run(const float* taps, float2* H, int ndata, int K, const FftTables& t, hipStream_t st) {
+    static hipError_t run(const float* taps, float2* Htmp, float2* Gs, int ndata, int K, const FftTables& t,
+                          hipStream_t st) {
         dim3 grid(K, ndata), block(WaveGeom<L>::NT);
-        hipLaunchKernelGGL(filter_kernel<L>, grid, block, 0, st, taps, H, K, t.tw, t.twa, t.twb);
+        hipLaunchKernelGGL(filter_kernel<L>, grid, block, 0, st, taps, Htmp, K, t.tw, t.twa, t.twb);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        dim3 grid2(K + 1, ndata), block2(256);
+        hipLaunchKernelGGL(make_g_kernel, grid2, block2, 0, st, Htmp, Gs, K, 1 << L);
         return hipGetLastError();
     }
 };
 
 }  // namespace
 
-hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool walker_ok,
-                          bool any_partial, hipStream_t st) {
-    return dispatch_log2p<FwdLaunch>(f.log2P, jobs, njobs, max_blocks, f, walker_ok, any_partial, st);
+hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
+                          hipStream_t st) {
+    return dispatch_log2p<FwdLaunch>(f.log2P, jobs, njobs, max_blocks, f, pairs_ok, st);
 }
 
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
@@ -879,57 +825,77 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
     return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, walker_ok, st);
 }
 
-hipError_t launch_filter_transform(const float* taps, float2* H, int ndata, int K, int log2P, const FftTables& t,
-                                   hipStream_t st) {
-    return dispatch_log2p<FilterLaunch>(log2P, taps, H, ndata, K, t, st);
+hipError_t launch_filter_transform(const float* taps, float2* Htmp, float2* Gs, int ndata, int K, int log2P,
+                                   const FftTables& t, hipStream_t st) {
+    return dispatch_log2p<FilterLaunch>(log2P, taps, Htmp, Gs, ndata, K, t, st);
 }
 
-// ---- twiddle buffer of a P-point engine: [ tw2P (2P) | stage A rows (3*N2) | stage B pass tables ] ----
+// ---- twiddle buffer of a P-point engine -----------------------------------------------------------
+//   [ tw2P (2P) | stage A rows of the P-point FFT (4*N2) | stage B pass tables |
+//     stage A rows of the 2P-point FFT (stereo form) | its stage B pass tables ]
 template <int L>
 struct TableLayout {
-    static hipError_t run(int* n_tw, int* n_twa, int* n_twb, int* n2, int* log2n2) {
-        *n_tw = 2 << L;
-        *n_twa = WaveGeom<L>::TWA;
-        *n_twb = WaveGeom<L>::TWB;
-        *n2 = WaveGeom<L>::N2;
-        *log2n2 = WaveGeom<L>::LOG2N2;
+    static hipError_t run(int* n) {      // n[0..4]: tw, twa, twb, twa2, twb2 entries; n[5], n[6]: N2, log2N2; n[7], n[8]: of 2P
+        n[0] = 2 << L;
+        n[1] = WaveGeom<L>::TWA;
+        n[2] = WaveGeom<L>::TWB;
+        n[5] = WaveGeom<L>::N2;
+        n[6] = WaveGeom<L>::LOG2N2;
+        if constexpr (L >= 9) {
+            n[3] = WaveGeom<L + 1>::TWA;
+            n[4] = WaveGeom<L + 1>::TWB;
+            n[7] = WaveGeom<L + 1>::N2;
+            n[8] = WaveGeom<L + 1>::LOG2N2;
+        } else {
+            n[3] = n[4] = n[7] = n[8] = 0;
+        }
         return hipSuccess;
     }
 };
 
 int fft_table_count(int log2P) {
-    int a, b, c, n2, l2;
-    if (dispatch_log2p<TableLayout>(log2P, &a, &b, &c, &n2, &l2) != hipSuccess) return 0;
-    return a + b + c;
+    int n[9];
+    if (dispatch_log2p<TableLayout>(log2P, n) != hipSuccess) return 0;
+    return n[0] + n[1] + n[2] + n[3] + n[4];
 }
 
-void fill_fft_tables(int log2P, float2* dst, int* off_twa, int* off_twb) {
-    int n_tw, n_twa, n_twb, N2, log2n2;
-    (void)dispatch_log2p<TableLayout>(log2P, &n_tw, &n_twa, &n_twb, &N2, &log2n2);
-    const double P = (double)(1 << log2P);
-    for (int k = 0; k < n_tw; ++k) {
-        const double a = -M_PI * (double)k / P;                       // exp(-2*pi*i*k/(2P))
-        dst[k] = float2{(float)cos(a), (float)sin(a)};
-    }
-    *off_twa = n_tw;
-    *off_twb = n_tw + n_twa;
-    if (n_twa) {
-        for (int row = 0, k1 = 1; row < 3; ++row, k1 *= 2)
-            for (int n2 = 0; n2 < N2; ++n2) {
-                const double a = -2.0 * M_PI * (double)n2 * (double)k1 / P;
-                dst[n_tw + row * N2 + n2] = float2{(float)cos(a), (float)sin(a)};
-            }
-    }
+namespace {
+void fill_stage_a(float2* dst, int N2, double N) {     // rows k1 = 1, 2, 4, 8: exp(-2*pi*i*n2*k1/N)
+    for (int row = 0, k1 = 1; row < 4; ++row, k1 *= 2)
+        for (int n2 = 0; n2 < N2; ++n2) {
+            const double a = -2.0 * M_PI * (double)n2 * (double)k1 / N;
+            dst[row * N2 + n2] = float2{(float)cos(a), (float)sin(a)};
+        }
+}
+void fill_stage_b(float2* dst, int log2n2) {
     const Plan pl = make_plan(log2n2);
-    float2* tb = dst + n_tw + n_twa;
     for (int p = 1; p < pl.n; ++p) {
         const int R = pl.r[p], NS = pl.ns[p];
         for (int r = 1; r < R; ++r)
             for (int k = 0; k < NS; ++k) {
                 const double a = -2.0 * M_PI * (double)k * (double)r / ((double)NS * (double)R);
-                tb[pl.off[p] + (r - 1) * NS + k] = float2{(float)cos(a), (float)sin(a)};
+                dst[pl.off[p] + (r - 1) * NS + k] = float2{(float)cos(a), (float)sin(a)};
             }
     }
+}
+}  // namespace
+
+void fill_fft_tables(int log2P, float2* dst, int off[4]) {
+    int n[9];
+    (void)dispatch_log2p<TableLayout>(log2P, n);
+    const double P = (double)(1 << log2P);
+    for (int k = 0; k < n[0]; ++k) {
+        const double a = -M_PI * (double)k / P;                       // exp(-2*pi*i*k/(2P))
+        dst[k] = float2{(float)cos(a), (float)sin(a)};
+    }
+    off[0] = n[0];                        // twa
+    off[1] = off[0] + n[1];               // twb
+    off[2] = off[1] + n[2];               // twa2 (or the end)
+    off[3] = off[2] + n[3];               // twb2
+    if (n[1]) fill_stage_a(dst + off[0], n[5], P);
+    fill_stage_b(dst + off[1], n[6]);
+    if (n[3]) fill_stage_a(dst + off[2], n[7], 2.0 * P);
+    if (n[4]) fill_stage_b(dst + off[3], n[8]);
 }
 
 // Variant choice: the sliding-window kernel when the call carries >= 4 blocks per

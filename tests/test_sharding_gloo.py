@@ -26,9 +26,13 @@ def test_shards_partition_the_streams():
 def test_world_size_2_gloo(tmp_path, oracle):
     out = os.path.join(str(tmp_path), "r.json")
     n_total = 7
+    import socket
+    with socket.socket() as sk:                 # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total)]
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total)]
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     r = json.load(open(out))
     assert r["units"] == n_total * 1000 and r["mine"] == [0, 2, 4, 6]

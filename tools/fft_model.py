@@ -151,3 +151,51 @@ if __name__ == "__main__":
         assert np.allclose(wave_fft(z), np.fft.fft(z))
         assert np.allclose(wave_fft(z, True), np.fft.ifft(z) * P)
     print("wave-autonomous decomposition ok")
+
+
+# ---------------------------------------------------------------------------
+# Model of the v3 pipeline identities:
+#   (a) zero-padded forward transforms:  X(n) = FFT([x(n-1) | x(n)]) = Z(n-1) + s*Z(n),
+#       Z(n) = FFT([x(n) | 0]), s_k = (-1)^k, so  Y(n) = sum_{j<=K} Z(n-j) * G(j),
+#       G(j) = s*H(j) + H(j-1)  (H(-1) = H(K) = 0)
+#   (b) stereo as one complex signal: FFT(L + iR) -> ZL, ZR by symmetry; IFFT(YL + i*YR) -> (yL, yR)
+# ---------------------------------------------------------------------------
+def check_v3(P=256, K=3, nb=7, seed=2):
+    rng = np.random.default_rng(seed)
+    N = 2 * P
+    h = rng.standard_normal((2, K * P))
+    x = rng.standard_normal((2, nb * P))
+    s = (-1.0) ** np.arange(P + 1)
+    H = [[np.fft.rfft(np.concatenate([h[c, j * P:(j + 1) * P], np.zeros(P)])) / N for j in range(K)] for c in range(2)]
+    G = [[(s * H[c][j] if j < K else 0) + (H[c][j - 1] if j >= 1 else 0) for j in range(K + 1)] for c in range(2)]
+    # (b) forward: one complex FFT for both channels of a zero-padded block
+    Zs = []
+    for n in range(nb):
+        z = np.concatenate([x[0, n * P:(n + 1) * P] + 1j * x[1, n * P:(n + 1) * P], np.zeros(P)])
+        Z = np.fft.fft(z)
+        k = np.arange(P + 1)
+        Zm = np.conj(Z[(N - k) % N])
+        ZL, ZR = 0.5 * (Z[k] + Zm), -0.5j * (Z[k] - Zm)
+        assert np.allclose(ZL, np.fft.rfft(np.concatenate([x[0, n * P:(n + 1) * P], np.zeros(P)])))
+        assert np.allclose(ZR, np.fft.rfft(np.concatenate([x[1, n * P:(n + 1) * P], np.zeros(P)])))
+        Zs.append((ZL, ZR))
+    y = np.zeros((2, nb * P))
+    for n in range(nb):
+        Y = [sum(Zs[n - j][c] * G[c][j] for j in range(K + 1) if n - j >= 0) for c in range(2)]
+        # (b) inverse: Z[k] = YL[k] + i YR[k] (k <= P), Z[N-k] = conj(YL[k]) + i conj(YR[k])
+        Zc = np.zeros(N, complex)
+        k = np.arange(P + 1)
+        Zc[k] = Y[0] + 1j * Y[1]
+        kk = np.arange(1, P)
+        Zc[N - kk] = np.conj(Y[0][kk]) + 1j * np.conj(Y[1][kk])
+        zt = np.fft.ifft(Zc) * N
+        y[0, n * P:(n + 1) * P] = zt.real[P:]
+        y[1, n * P:(n + 1) * P] = zt.imag[P:]
+    for c in range(2):
+        assert np.allclose(y[c], np.convolve(x[c], h[c])[: nb * P])
+    return True
+
+
+if __name__ == "__main__":
+    assert check_v3() and check_v3(P=64, K=1, nb=4) and check_v3(P=128, K=5, nb=3)
+    print("v3 identities (zero-padded transforms, G filter, dual-real stereo) ok")
