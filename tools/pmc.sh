@@ -17,7 +17,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         key = None
-        for k in ("forward_kernel", "mac_slide_kernel", "mac_kernel", "inverse_kernel", "forward_walker_kernel", "inverse_walker_kernel"):
+        for k in ("forward_kernel", "mac_slide_kernel", "mac_kernel", "inverse_kernel", "forward_walker_kernel", "inverse_walker_kernel", "forward_dual_kernel"):
             if k in n: key = k
         if not key: continue
         key += " grid=" + row["Grid_Size"]
