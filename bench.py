@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--taps", type=int, default=262144)
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU baseline sample length")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline sample length")
     args = ap.parse_args()
 
     import torch
@@ -199,8 +199,10 @@ def main():
         cores = os.cpu_count() or 1
         nthreads = cores
         nstreams = nthreads
-        tprobe = O.bench_streams(nstreams, 4, nthreads, C, C, size, 3) / 4.0      # seconds per block round
-        nblocks = int(max(4, min(4096, args.cpu_seconds / max(tprobe, 1e-4))))
+        # a short probe runs ~2.5x faster per block than the steady state (cold DRAM working set of
+        # 8 MB per stream builds up), so size the sample from a 16-block probe
+        tprobe = O.bench_streams(nstreams, 16, nthreads, C, C, size, 3) / 16.0    # seconds per block round
+        nblocks = int(max(8, min(4096, args.cpu_seconds / max(tprobe * 1.5, 1e-4))))
         tcpu = O.bench_streams(nstreams, nblocks, nthreads, C, C, size, 3)
         cpu = {"value": round(nstreams * nblocks * P * C / tcpu / 1e6, 2), "unit": "Msamples/s", "cores": nthreads,
                "kind": "port",
