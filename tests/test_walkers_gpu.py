@@ -1,6 +1,7 @@
-"""GPU: batches large enough (>= 256 blocks per launch) to take the pair-walker kernels
-(forward_walker_kernel<11|12|13, 1|2>, inverse_walker_kernel<13, 1|2>), against the oracle and
-against the general kernels (same streams run in small batches)."""
+"""GPU: large batches (>= 256 blocks per launch) through the fast kernel forms — the stereo forward
+transform (forward_dual_kernel<11|12|13>: one 2P-point complex FFT per block), the mono forward path,
+and the inverse pair-walker (inverse_walker_kernel<13, 1|2>) — against the oracle and against the
+general kernels (the same streams run one at a time in small calls)."""
 import numpy as np
 import pytest
 
@@ -17,14 +18,14 @@ def _rms(a):
 
 
 @pytest.mark.parametrize("channels,size,nstreams,nblocks", [
-    (2, 20000, 16, 17),     # P = 8192, K = 3: forward_walker<13,2> + inverse_walker<13,2>
-    (1, 20000, 16, 17),     # mono: <13,1> both
-    (2, 4000, 16, 20),      # P = 4096: forward_walker<12,2>, general inverse
+    (2, 20000, 16, 17),     # P = 8192, K = 3: forward_dual<13> + inverse_walker<13,2>
+    (1, 20000, 16, 17),     # mono: general forward + inverse_walker<13,1>
+    (2, 4000, 16, 20),      # P = 4096: forward_dual<12>, general inverse
     (1, 3000, 20, 16),      # P = 4096 mono
-    (2, 1500, 32, 12),      # P = 2048: forward_walker<11,2>
+    (2, 1500, 32, 12),      # P = 2048: forward_dual<11>
     (1, 2000, 16, 20),      # P = 2048 mono
 ])
-def test_walker_batches_match_oracle_and_general_kernels(engine, oracle, channels, size, nstreams, nblocks):
+def test_large_batches_match_oracle_and_general_kernels(engine, oracle, channels, size, nstreams, nblocks):
     rng = np.random.default_rng(size + channels)
     paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(channels)}
     if channels == 2:
@@ -35,7 +36,7 @@ def test_walker_batches_match_oracle_and_general_kernels(engine, oracle, channel
     lens = [nblocks * P - (0 if s % 3 else 1234 + s) for s in range(nstreams)]              # some ragged tails
     xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
     big = [flt.open_stream(nblocks) for _ in range(nstreams)]
-    ys = fa.batch_process(big, xs)                                   # one launch round: walkers
+    ys = fa.batch_process(big, xs)                                   # one launch round: fast forms
     hd = dense_taps(paths, size)
     for s in (0, 1, nstreams - 1):
         sp.reset()
@@ -73,7 +74,7 @@ def test_unaligned_device_pointers_fall_back_to_general_kernels(engine, oracle):
     sa = [flt.open_stream(T) for _ in range(S)]
     su = [flt.open_stream(T) for _ in range(S)]
     aligned_in = [xd[s, :T * P].contiguous() for s in range(S)]
-    fa.batch_process(sa, aligned_in, [out_a[s] for s in range(S)], device=True)             # walkers
+    fa.batch_process(sa, aligned_in, [out_a[s] for s in range(S)], device=True)             # fast forms
     # views starting one frame (8 bytes) into the buffers: not 16-byte aligned
     fa.batch_process(su, [xd[s, 1:] for s in range(S)], [out_u[s, 1:] for s in range(S)], device=True)
     ya = out_a.cpu().numpy()
