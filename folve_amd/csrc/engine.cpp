@@ -45,6 +45,12 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kJobSlots = 8;
 
+// Frees a temporary device allocation on every exit path.
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+};
+
 }  // namespace
 
 struct TableOffsets { int o[4]; int total; };
@@ -554,9 +560,9 @@ int fe_filter_commit(fe_filter* f) {
         const size_t gper = (size_t)(K + 1) * P;       // G rows per data path
         // populated rows of G(j) = s*H(j) + H(j-1): wherever H(j) or H(j-1) is populated
         std::vector<uint64_t> masks((size_t)f->ndata * 4, 0);
-        float* taps_dev = nullptr;
-        float2* h_tmp = nullptr;
-        HIP_TRY(hipMalloc((void**)&taps_dev, per * f->ndata * sizeof(float)));
+        DevTmp taps_tmp, spectra_tmp;          // taps and the H rows live only until G exists
+        HIP_TRY(hipMalloc(&taps_tmp.p, per * f->ndata * sizeof(float)));
+        float* taps_dev = static_cast<float*>(taps_tmp.p);
         for (int d = 0; d < f->ndata; ++d) {
             const PathHost& p = f->paths[(size_t)owners[(size_t)d]];
             for (int j = 0; j <= K; ++j) {
@@ -565,16 +571,15 @@ int fe_filter_commit(fe_filter* f) {
                 if (hj || hp) masks[(size_t)d * 4 + (size_t)(j >> 6)] |= 1ull << (j & 63);
             }
             hipError_t r = hipMemcpy(taps_dev + per * d, p.taps.data(), per * sizeof(float), hipMemcpyHostToDevice);
-            if (r != hipSuccess) { (void)hipFree(taps_dev); return fail(FE_ERR_DEVICE, "tap upload: %s", hipGetErrorString(r)); }
+            if (r != hipSuccess) return fail(FE_ERR_DEVICE, "tap upload: %s", hipGetErrorString(r));
         }
-        HIP_TRY(hipMalloc((void**)&h_tmp, per * f->ndata * sizeof(float2)));
+        HIP_TRY(hipMalloc(&spectra_tmp.p, per * f->ndata * sizeof(float2)));
+        float2* h_tmp = static_cast<float2*>(spectra_tmp.p);
         HIP_TRY(hipMalloc((void**)&f->H, gper * f->ndata * sizeof(float2)));
         HIP_TRY(hipMalloc((void**)&f->mask_dev, masks.size() * sizeof(uint64_t)));
         HIP_TRY(hipMemcpy(f->mask_dev, masks.data(), masks.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(fk::launch_filter_transform(taps_dev, h_tmp, f->H, f->ndata, K, f->log2P, tabs, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        HIP_TRY(hipFree(taps_dev));
-        HIP_TRY(hipFree(h_tmp));
     }
     f->dev.cin = f->ninp; f->dev.cout = f->nout; f->dev.P = P; f->dev.log2P = f->log2P; f->dev.K = K + 1;   // rows of G
     f->dev.H = f->H; f->dev.mask = f->mask_dev; f->dev.paths = f->paths_dev; f->dev.out_first = f->out_first_dev;

@@ -13,7 +13,8 @@
  * different threads; a committed filter is immutable and shareable.
  *
  * There is NO CPU fallback: without a usable HIP device every compute entry
- * point fails with FE_ERR_DEVICE.
+ * point fails with FE_ERR_DEVICE.  After FE_ERR_DEVICE from a processing call the
+ * convolver state of the streams in that call is undefined: reset or close them.
  */
 #ifndef FOLVE_ENGINE_H
 #define FOLVE_ENGINE_H
