@@ -25,10 +25,84 @@ struct float4 { float x, y, z, w; };
 
 namespace fk {
 
+// ---- complex arithmetic ---------------------------------------------------------
+// Device code: a complex number is a VGPR pair and every operation below is ONE or TWO packed
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), the swaps, broadcasts and sign
+// flips of complex arithmetic expressed by op_sel / op_sel_hi / neg_lo / neg_hi instead of
+// v_mov / v_xor.  hipcc finds only part of this from scalar source (a radix-16 butterfly:
+// 138 VALU instructions from the scalar form, 88 from this one).  Host code (the CPU check of
+// the butterflies, tests/host_fft_check.cpp) compiles the scalar forms.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float fk_v2f __attribute__((ext_vector_type(2)));
+#define FK_V(a) (fk_v2f{(a).x, (a).y})
+#define FK_F2(v) (float2{(v).x, (v).y})
+FK_HD float2 cadd(float2 a, float2 b) { const fk_v2f r = FK_V(a) + FK_V(b); return FK_F2(r); }
+FK_HD float2 csub(float2 a, float2 b) { const fk_v2f r = FK_V(a) - FK_V(b); return FK_F2(r); }
+// a + i*b, a - i*b
+FK_HD float2 cadd_i(float2 a, float2 b) {
+    fk_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)));
+    return FK_F2(r);
+}
+FK_HD float2 csub_i(float2 a, float2 b) {
+    fk_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)));
+    return FK_F2(r);
+}
+// a + conj(b), a - conj(b)
+FK_HD float2 cadd_conj(float2 a, float2 b) {
+    fk_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)));
+    return FK_F2(r);
+}
+FK_HD float2 csub_conj(float2 a, float2 b) {
+    fk_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)));
+    return FK_F2(r);
+}
+// conj(a) + i*conj(b) = conj(a - i*b)
+FK_HD float2 conj_csub_i(float2 a, float2 b) {
+    fk_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)));
+    return FK_F2(r);
+}
+// a * b
+FK_HD float2 cmul(float2 a, float2 b) {
+    fk_v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(FK_V(a)), "v"(FK_V(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)), "v"(t));
+    return FK_F2(r);
+}
+// a * conj(b)
+FK_HD float2 cmulc(float2 a, float2 b) {
+    fk_v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(FK_V(a)), "v"(FK_V(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)), "v"(t));
+    return FK_F2(r);
+}
+// a * (wr + i*wi), wr and wi known at compile time
+FK_HD float2 cmul_const(float2 a, float wr, float wi) {
+    const fk_v2f t = FK_V(a) * wr;
+    const fk_v2f ws = fk_v2f{wi, wi};
+    fk_v2f r;                                             // r.lo = t.lo - a.hi*wi,  r.hi = t.hi + a.lo*wi
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(FK_V(a)), "v"(ws), "v"(t));
+    return FK_F2(r);
+}
+#else
 FK_HD float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }
 FK_HD float2 csub(float2 a, float2 b) { return float2{a.x - b.x, a.y - b.y}; }
+FK_HD float2 cadd_i(float2 a, float2 b) { return float2{a.x - b.y, a.y + b.x}; }
+FK_HD float2 csub_i(float2 a, float2 b) { return float2{a.x + b.y, a.y - b.x}; }
+FK_HD float2 cadd_conj(float2 a, float2 b) { return float2{a.x + b.x, a.y - b.y}; }
+FK_HD float2 csub_conj(float2 a, float2 b) { return float2{a.x - b.x, a.y + b.y}; }
+FK_HD float2 conj_csub_i(float2 a, float2 b) { return float2{a.x + b.y, -a.y + b.x}; }
 FK_HD float2 cmul(float2 a, float2 b) { return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 FK_HD float2 cmulc(float2 a, float2 b) { return float2{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
+FK_HD float2 cmul_const(float2 a, float wr, float wi) { return float2{a.x * wr - a.y * wi, a.x * wi + a.y * wr}; }
+#endif
 
 // 16th roots of unity: cos/sin(2*pi*i/16), i = 0..7.
 constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
@@ -36,30 +110,26 @@ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0
 constexpr float kSin16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
                              1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
 
-// x * exp(-/+ 2*pi*i*IDX/16)  (INV: +)
-template <int IDX, bool INV>
-FK_HD float2 mul_w16(float2 x) {
-    if constexpr (IDX == 0) {
-        return x;
-    } else if constexpr (IDX == 4) {
-        return INV ? float2{-x.y, x.x} : float2{x.y, -x.x};
-    } else {
-        constexpr float wr = kCos16[IDX];
-        constexpr float wi = INV ? kSin16[IDX] : -kSin16[IDX];
-        return float2{x.x * wr - x.y * wi, x.x * wi + x.y * wr};
-    }
-}
-
 template <int R, bool INV>
 FK_HD void dft(float2 (&v)[R]);
 
+// v[K], v[K + R/2] = e[K] +/- o[K] * exp(-/+ 2*pi*i*K/R)  (INV: +); the quarter turn is part of the add
 template <int R, bool INV, int... K>
 FK_HD void dft_combine(float2 (&v)[R], const float2 (&e)[R / 2], const float2 (&o)[R / 2],
                        std::integer_sequence<int, K...>) {
     ((void)([&] {
-         const float2 t = mul_w16<K * 16 / R, INV>(o[K]);
-         v[K] = cadd(e[K], t);
-         v[K + R / 2] = csub(e[K], t);
+         constexpr int IDX = K * 16 / R;
+         if constexpr (IDX == 0) {
+             v[K] = cadd(e[K], o[K]);
+             v[K + R / 2] = csub(e[K], o[K]);
+         } else if constexpr (IDX == 4) {
+             v[K] = INV ? cadd_i(e[K], o[K]) : csub_i(e[K], o[K]);
+             v[K + R / 2] = INV ? csub_i(e[K], o[K]) : cadd_i(e[K], o[K]);
+         } else {
+             const float2 t = cmul_const(o[K], kCos16[IDX], INV ? kSin16[IDX] : -kSin16[IDX]);
+             v[K] = cadd(e[K], t);
+             v[K + R / 2] = csub(e[K], t);
+         }
      }()),
      ...);
 }

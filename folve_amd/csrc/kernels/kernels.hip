@@ -27,6 +27,29 @@
 
 namespace fk {
 
+#ifdef FOLVE_PHASE_TRACE
+// TRACE build only (make TRACE=1): cycles per phase, summed over workgroups by thread 0.
+__device__ unsigned long long g_phase[2][8];
+#define PH_INIT() unsigned long long ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH(i)                                                     \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        const unsigned long long ph_n = clock64();                \
+        ph_acc[i] += ph_n - ph_t;                                 \
+        ph_t = ph_n;                                              \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+#define PH_FLUSH(kid)                                             \
+    do {                                                          \
+        if (threadIdx.x == 0)                                     \
+            for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase[kid][ph_i], ph_acc[ph_i]); \
+    } while (0)
+#else
+#define PH_INIT() do {} while (0)
+#define PH(i) do {} while (0)
+#define PH_FLUSH(kid) do {} while (0)
+#endif
+
 namespace {
 
 // complex multiply-accumulate on two packed bins
@@ -163,6 +186,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
     const int tid = threadIdx.x;
     const float2* __restrict__ pcm = reinterpret_cast<const float2*>(job.in) + (size_t)b * P;   // frame t: (L, R)
     const long long left = job.nframes - (long long)b * P;                                      // valid frames
+    PH_INIT();
 
     float2 v[COLS][N1];
 #pragma unroll
@@ -182,9 +206,13 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
         if (GUARD && n2 >= N2) continue;
         stage_a_column<LOG2P + 1, false>(s, f.twa2, n2, v[c]);
     }
+    PH(0);                                                // PCM wait + stage A
     __syncthreads();
+    PH(1);
     stage_b<LOG2P + 1, false>(s, f.twb2, tid);
+    PH(2);
     __syncthreads();
+    PH(3);
     const int slot = ring_slot(job.slot0, b, job.ring);
     float2* __restrict__ rowL = job.fdl + ((size_t)0 * job.ring + slot) * P;
     float2* __restrict__ rowR = job.fdl + ((size_t)1 * job.ring + slot) * P;
@@ -204,6 +232,8 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
             gst(rowR + k, float2{0.5f * (a.y + bb.y), -0.5f * (a.x - bb.x)});
         }
     }
+    PH(4);                                                // split + stores issued
+    PH_FLUSH(0);
 }
 
 // ---------------------------------------------------------------------------
@@ -300,11 +330,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
 #pragma unroll
                 for (int n1 = 0; n1 < N1; ++n1) {
                     const float2 a = ya[q][n1], bb = yb[q][N1 - 1 - n1];
-                    const float2 e = float2{a.x + bb.x, a.y - bb.y};
-                    const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                    const float2 e = cadd_conj(a, bb);
+                    const float2 dd = csub_conj(a, bb);
                     const float2 oo = cmulc(dd, wa[q][n1]);
-                    za[n1] = float2{e.x - oo.y, e.y + oo.x};
-                    zb[N1 - 1 - n1] = float2{e.x + oo.y, -e.y + oo.x};
+                    za[n1] = cadd_i(e, oo);
+                    zb[N1 - 1 - n1] = conj_csub_i(e, oo);
                 }
             } else {
                 // column 0: k = n1*N2 <-> (N1-n1)*N2 (k = 0 is the packed (DC, Nyquist) bin);
@@ -316,16 +346,16 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
                         za[0] = float2{y0.x + y0.y, y0.x - y0.y};
                     } else {
                         const float2 a = ya[q][n1], bb = ya[q][N1 - n1];
-                        const float2 e = float2{a.x + bb.x, a.y - bb.y};
-                        const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                        const float2 e = cadd_conj(a, bb);
+                        const float2 dd = csub_conj(a, bb);
                         const float2 oo = cmulc(dd, wa[q][n1]);
-                        za[n1] = float2{e.x - oo.y, e.y + oo.x};
+                        za[n1] = cadd_i(e, oo);
                     }
                     const float2 a = yb[q][n1], bb = yb[q][N1 - 1 - n1];
-                    const float2 e = float2{a.x + bb.x, a.y - bb.y};
-                    const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                    const float2 e = cadd_conj(a, bb);
+                    const float2 dd = csub_conj(a, bb);
                     const float2 oo = cmulc(dd, tw[n1 * N2 + N2 / 2]);
-                    zb[n1] = float2{e.x - oo.y, e.y + oo.x};
+                    zb[n1] = cadd_i(e, oo);
                 }
             }
             const int ca = p, cb = (p == 0) ? N2 / 2 : N2 - p;
@@ -436,6 +466,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     float* __restrict__ out = job.out;
     float pk_s = 0.0f, pk_a = 0.0f;
     float2 zl[OUTS];                                          // first channel's samples of the block
+    PH_INIT();
 
 #pragma unroll 1
     for (int u = 0; u < nunits; ++u) {
@@ -450,11 +481,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
 #pragma unroll
             for (int n1 = 0; n1 < N1; ++n1) {
                 const float2 a = ya[n1], bb = yb[N1 - 1 - n1];
-                const float2 e = float2{a.x + bb.x, a.y - bb.y};
-                const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                const float2 e = cadd_conj(a, bb);
+                const float2 dd = csub_conj(a, bb);
                 const float2 oo = cmulc(dd, wa[n1]);
-                za[n1] = float2{e.x - oo.y, e.y + oo.x};
-                zb[N1 - 1 - n1] = float2{e.x + oo.y, -e.y + oo.x};
+                za[n1] = cadd_i(e, oo);
+                zb[N1 - 1 - n1] = conj_csub_i(e, oo);
             }
         } else {
 #pragma unroll
@@ -464,18 +495,19 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
                     za[0] = float2{y0.x + y0.y, y0.x - y0.y};
                 } else {
                     const float2 a = ya[n1], bb = ya[N1 - n1];
-                    const float2 e = float2{a.x + bb.x, a.y - bb.y};
-                    const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                    const float2 e = cadd_conj(a, bb);
+                    const float2 dd = csub_conj(a, bb);
                     const float2 oo = cmulc(dd, wa[n1]);
-                    za[n1] = float2{e.x - oo.y, e.y + oo.x};
+                    za[n1] = cadd_i(e, oo);
                 }
                 const float2 a = yb[n1], bb = yb[N1 - 1 - n1];
-                const float2 e = float2{a.x + bb.x, a.y - bb.y};
-                const float2 dd = float2{a.x - bb.x, a.y + bb.y};
+                const float2 e = cadd_conj(a, bb);
+                const float2 dd = csub_conj(a, bb);
                 const float2 oo = cmulc(dd, tw[n1 * N2 + N2 / 2]);
-                zb[n1] = float2{e.x - oo.y, e.y + oo.x};
+                zb[n1] = cadd_i(e, oo);
             }
         }
+        PH(0);                                                // Y row wait + fold
         if (u + 1 < nunits) {                                 // the next row flies during this FFT
             const float2* __restrict__ y = row_of(u + 1);
 #pragma unroll
@@ -483,9 +515,13 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
         }
         stage_a_column<LOG2P, true>(s, atw_a, t, za);
         stage_a_column<LOG2P, true>(s, atw_b, (t == 0) ? N2 / 2 : N2 - t, zb);
+        PH(1);
         __syncthreads();
+        PH(2);
         stage_b<LOG2P, true>(s, twb_l, t);
+        PH(3);
         __syncthreads();
+        PH(4);
         // ---- transposed read: consecutive lanes take consecutive output frames ----
         const long long fb = (long long)b * P;
         const bool whole = (fb + P <= job.nframes);
@@ -528,8 +564,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
                 }
             }
         }
+        PH(5);
         __syncthreads();                                      // the image is rewritten by the next stage A
+        PH(6);
     }
+    PH_FLUSH(1);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         pk_s = fmaxf(pk_s, __shfl_xor(pk_s, off, 64));
@@ -765,7 +804,8 @@ struct FwdLaunch {
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
                           hipStream_t st) {
         if constexpr (L >= 9) {                           // 2P >= 1024: the stereo transform exists
-            if (f.cin == 2 && pairs_ok && f.twa2) {
+            static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
+            if (f.cin == 2 && pairs_ok && f.twa2 && !generic) {
                 dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
                 hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
                 return hipGetLastError();
@@ -784,7 +824,8 @@ struct InvLaunch {
         constexpr int NT = WaveGeom<L>::NT;
         if constexpr (L == 13) {      // P = 8192 (every filter longer than 4096 taps): one column pair per thread
             // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
-            if (pairs_ok && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
+            static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
+            if (pairs_ok && !generic && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
                 static const char* rl = getenv("FOLVE_AMD_RUNLEN");
                 int runlen = rl ? atoi(rl) : 8;
                 while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
@@ -949,3 +990,15 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
 }
 
 }  // namespace fk
+
+#ifdef FOLVE_PHASE_TRACE
+// kernel 0 = forward_dual, 1 = inverse_walker; out[16]; reset != 0 clears the counters afterwards
+extern "C" int fe_debug_phases(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fk::g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        static const unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fk::g_phase), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
