@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "fft_core.hpp"
 
 namespace fk {
@@ -408,6 +410,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     }
 }
 
+// e^(+i*pi*k/P) at k = n1*N2 + N2/2 for P = 8192 (N1 = 8): the fold twiddles of the self-paired middle
+// column are the odd 32nd roots of unity — constants, so the walkers' loops hold no table load.
+constexpr float kMidCos8[8] = {0.98078528040323043f, 0.83146961230254524f, 0.55557023301960229f, 0.19509032201612833f, -0.19509032201612819f, -0.55557023301960196f, -0.83146961230254535f, -0.98078528040323043f};
+constexpr float kMidSin8[8] = {0.19509032201612825f, 0.55557023301960218f, 0.83146961230254524f, 0.98078528040323043f, 0.98078528040323043f, 0.83146961230254546f, 0.55557023301960218f, 0.19509032201612861f};
+
 // ---------------------------------------------------------------------------
 // K3, fast form ("pair-walker"): mono / stereo output, P = 8192.
 // grid (runs of `run` consecutive blocks, 1, streams)
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
-    static_assert(N1 >= 2 && NT == N2 / 2, "walker needs P = 8192 (one column pair per thread)");
+    static_assert(N1 == 8 && NT == N2 / 2, "walker needs P = 8192 (one column pair per thread)");
     constexpr int OUTS = (P / 2) / NT;                        // output complex samples per thread (8)
     // LDS: the FFT image, then the stage-B pass tables.  One workgroup fits per CU anyway
     // (registers), so the spare LDS is free; with the tables there the loop waits on vmcnt only for
@@ -452,122 +459,128 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     const StageATw<LOG2P> atw_a = load_stage_a_tw<LOG2P>(f.twa, ca);   // loop-invariant: kept in registers
     const StageATw<LOG2P> atw_b = load_stage_a_tw<LOG2P>(f.twa, cb);
 
-    const int nunits = (b1 - b0) * COUT;                      // unit u = (block, channel), channel fastest
-    auto row_of = [&](int u) {
-        const int b = b0 + u / COUT, o = u % COUT;
-        return Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P;
-    };
+    auto row_of = [&](int b, int o) { return Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P; };
     float2 ya[N1], yb[N1];
-    {
-        const float2* __restrict__ y = row_of(0);
+    auto request = [&](const float2* __restrict__ y) {
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) { ya[n1] = y[n1 * N2 + ca]; yb[n1] = y[n1 * N2 + cb]; }
-    }
+    };
+    request(row_of(b0, 0));
     float* __restrict__ out = job.out;
     float pk_s = 0.0f, pk_a = 0.0f;
-    float2 zl[OUTS];                                          // first channel's samples of the block
     PH_INIT();
 
-#pragma unroll 1
-    for (int u = 0; u < nunits; ++u) {
-        // Opaque copy of the thread index: keeps the (cheap) LDS / table address arithmetic of the FFT
-        // inside the loop instead of hoisted into ~100 loop-invariant registers.
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        const int b = b0 + u / COUT, o = u % COUT;
-        // ---- Hermitian fold in registers (see inverse_kernel) ----
-        float2 za[N1], zb[N1];
-        if (t != 0) {
+    // One block, all of its channels.  WHOLE: every frame of the block exists — true for all
+    // blocks but a stream's last.  The loop over whole blocks issues a FIXED number of loads and
+    // stores per trip, so the wait for a prefetched row is an exact vmcnt(N) that leaves the
+    // block's stores in flight; with a data-dependent store count hipcc falls back to vmcnt(0)
+    // and every wave idles for a store round trip per block.
+    auto do_block = [&]<bool WHOLE>(std::bool_constant<WHOLE>, int b) {
+        float2 zl[OUTS];                                      // first channel's samples of the block
 #pragma unroll
-            for (int n1 = 0; n1 < N1; ++n1) {
-                const float2 a = ya[n1], bb = yb[N1 - 1 - n1];
-                const float2 e = cadd_conj(a, bb);
-                const float2 dd = csub_conj(a, bb);
-                const float2 oo = cmulc(dd, wa[n1]);
-                za[n1] = cadd_i(e, oo);
-                zb[N1 - 1 - n1] = conj_csub_i(e, oo);
-            }
-        } else {
+        for (int o = 0; o < COUT; ++o) {
+            // Opaque copy of the thread index: keeps the (cheap) LDS / table address arithmetic of the
+            // FFT inside the loop instead of hoisted into ~100 loop-invariant registers.
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            // ---- Hermitian fold in registers (see inverse_kernel) ----
+            float2 za[N1], zb[N1];
+            if (t != 0) {
 #pragma unroll
-            for (int n1 = 0; n1 < N1; ++n1) {
-                if (n1 == 0) {
-                    const float2 y0 = ya[0];
-                    za[0] = float2{y0.x + y0.y, y0.x - y0.y};
-                } else {
-                    const float2 a = ya[n1], bb = ya[N1 - n1];
+                for (int n1 = 0; n1 < N1; ++n1) {
+                    const float2 a = ya[n1], bb = yb[N1 - 1 - n1];
                     const float2 e = cadd_conj(a, bb);
                     const float2 dd = csub_conj(a, bb);
                     const float2 oo = cmulc(dd, wa[n1]);
                     za[n1] = cadd_i(e, oo);
+                    zb[N1 - 1 - n1] = conj_csub_i(e, oo);
                 }
-                const float2 a = yb[n1], bb = yb[N1 - 1 - n1];
-                const float2 e = cadd_conj(a, bb);
-                const float2 dd = csub_conj(a, bb);
-                const float2 oo = cmulc(dd, tw[n1 * N2 + N2 / 2]);
-                zb[n1] = cadd_i(e, oo);
-            }
-        }
-        PH(0);                                                // Y row wait + fold
-        if (u + 1 < nunits) {                                 // the next row flies during this FFT
-            const float2* __restrict__ y = row_of(u + 1);
+            } else {
 #pragma unroll
-            for (int n1 = 0; n1 < N1; ++n1) { ya[n1] = y[n1 * N2 + ca]; yb[n1] = y[n1 * N2 + cb]; }
-        }
-        stage_a_column<LOG2P, true>(s, atw_a, t, za);
-        stage_a_column<LOG2P, true>(s, atw_b, (t == 0) ? N2 / 2 : N2 - t, zb);
-        PH(1);
-        __syncthreads();
-        PH(2);
-        stage_b<LOG2P, true>(s, twb_l, t);
-        PH(3);
-        __syncthreads();
-        PH(4);
-        // ---- transposed read: consecutive lanes take consecutive output frames ----
-        const long long fb = (long long)b * P;
-        const bool whole = (fb + P <= job.nframes);
-        if (COUT == 2 && o == 0) {
-#pragma unroll
-            for (int c = 0; c < OUTS; ++c) zl[c] = s[G::at(P / 2 + t + c * NT)];
-        } else {
-#pragma unroll
-            for (int c = 0; c < OUTS; ++c) {
-                const int q = P / 2 + t + c * NT;             // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
-                const float2 z = s[G::at(q)];
-                const long long fr = fb + 2 * q - P;
-                if constexpr (COUT == 2) {
-                    const float2 l = zl[c];
-                    if (whole) {
-                        gst(reinterpret_cast<float4*>(out + fr * 2), float4{l.x, z.x, l.y, z.y});
-                        pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
-                        pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
+                for (int n1 = 0; n1 < N1; ++n1) {
+                    if (n1 == 0) {
+                        const float2 y0 = ya[0];
+                        za[0] = float2{y0.x + y0.y, y0.x - y0.y};
                     } else {
-                        if (fr < job.nframes) {
-                            gst(out + fr * 2, l.x); gst(out + fr * 2 + 1, z.x);
-                            pk_s = fmaxf(pk_s, fmaxf(l.x, z.x));
-                            pk_a = fmaxf(pk_a, fmaxf(fabsf(l.x), fabsf(z.x)));
-                        }
-                        if (fr + 1 < job.nframes) {
-                            gst(out + fr * 2 + 2, l.y); gst(out + fr * 2 + 3, z.y);
-                            pk_s = fmaxf(pk_s, fmaxf(l.y, z.y));
-                            pk_a = fmaxf(pk_a, fmaxf(fabsf(l.y), fabsf(z.y)));
-                        }
+                        const float2 a = ya[n1], bb = ya[N1 - n1];
+                        const float2 e = cadd_conj(a, bb);
+                        const float2 dd = csub_conj(a, bb);
+                        const float2 oo = cmulc(dd, wa[n1]);
+                        za[n1] = cadd_i(e, oo);
                     }
-                } else {
-                    if (whole) {
-                        gst(reinterpret_cast<float2*>(out + fr), z);
-                        pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
-                        pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
-                    } else {
-                        if (fr < job.nframes) { gst(out + fr, z.x); pk_s = fmaxf(pk_s, z.x); pk_a = fmaxf(pk_a, fabsf(z.x)); }
-                        if (fr + 1 < job.nframes) { gst(out + fr + 1, z.y); pk_s = fmaxf(pk_s, z.y); pk_a = fmaxf(pk_a, fabsf(z.y)); }
-                    }
+                    const float2 a = yb[n1], bb = yb[N1 - 1 - n1];
+                    const float2 e = cadd_conj(a, bb);
+                    const float2 dd = csub_conj(a, bb);
+                    const float2 oo = cmul_const(dd, kMidCos8[n1], kMidSin8[n1]);
+                    zb[n1] = cadd_i(e, oo);
                 }
             }
+            PH(0);                                            // Y row wait + fold
+            // The next row flies during this FFT.  The loads are unconditional so that the trip's
+            // memory-operation count is fixed; after the walk's last row they read the (cache-resident,
+            // 2P-entry) twiddle table instead of a row, and the values are never used.
+            if (o + 1 < COUT) request(row_of(b, o + 1));
+            else request(b + 1 < b1 ? row_of(b + 1, 0) : tw);
+            stage_a_column<LOG2P, true>(s, atw_a, t, za);
+            stage_a_column<LOG2P, true>(s, atw_b, (t == 0) ? N2 / 2 : N2 - t, zb);
+            PH(1);
+            __syncthreads();
+            PH(2);
+            stage_b<LOG2P, true>(s, twb_l, t);
+            PH(3);
+            __syncthreads();
+            PH(4);
+            // ---- transposed read: consecutive lanes take consecutive output frames ----
+            const long long fb = (long long)b * P;
+            if (COUT == 2 && o == 0) {
+#pragma unroll
+                for (int c = 0; c < OUTS; ++c) zl[c] = s[G::at(P / 2 + t + c * NT)];
+            } else {
+#pragma unroll
+                for (int c = 0; c < OUTS; ++c) {
+                    const int q = P / 2 + t + c * NT;         // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
+                    const float2 z = s[G::at(q)];
+                    const long long fr = fb + 2 * q - P;
+                    if constexpr (COUT == 2) {
+                        const float2 l = zl[c];
+                        if constexpr (WHOLE) {
+                            gst(reinterpret_cast<float4*>(out + fr * 2), float4{l.x, z.x, l.y, z.y});
+                            pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
+                            pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
+                        } else {
+                            if (fr < job.nframes) {
+                                gst(out + fr * 2, l.x); gst(out + fr * 2 + 1, z.x);
+                                pk_s = fmaxf(pk_s, fmaxf(l.x, z.x));
+                                pk_a = fmaxf(pk_a, fmaxf(fabsf(l.x), fabsf(z.x)));
+                            }
+                            if (fr + 1 < job.nframes) {
+                                gst(out + fr * 2 + 2, l.y); gst(out + fr * 2 + 3, z.y);
+                                pk_s = fmaxf(pk_s, fmaxf(l.y, z.y));
+                                pk_a = fmaxf(pk_a, fmaxf(fabsf(l.y), fabsf(z.y)));
+                            }
+                        }
+                    } else {
+                        if constexpr (WHOLE) {
+                            gst(reinterpret_cast<float2*>(out + fr), z);
+                            pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
+                            pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
+                        } else {
+                            if (fr < job.nframes) { gst(out + fr, z.x); pk_s = fmaxf(pk_s, z.x); pk_a = fmaxf(pk_a, fabsf(z.x)); }
+                            if (fr + 1 < job.nframes) { gst(out + fr + 1, z.y); pk_s = fmaxf(pk_s, z.y); pk_a = fmaxf(pk_a, fabsf(z.y)); }
+                        }
+                    }
+                }
+            }
+            PH(5);
+            __syncthreads();                                  // the image is rewritten by the next stage A
+            PH(6);
         }
-        PH(5);
-        __syncthreads();                                      // the image is rewritten by the next stage A
-        PH(6);
-    }
+    };
+
+    const int bw = (int)min((long long)b1, max((long long)b0, job.nframes / P));   // blocks [b0, bw) are whole
+#pragma unroll 1
+    for (int b = b0; b < bw; ++b) do_block(std::true_type{}, b);
+    if (bw < b1) do_block(std::false_type{}, bw);             // a stream's short last block
     PH_FLUSH(1);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -708,14 +721,25 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
     using V = typename BinVec<NB>::type;
     const StreamJob job = jobs[blockIdx.z];
     const int o = blockIdx.y / tiles;
-    const int t0 = (blockIdx.y - o * tiles) * TT;
+    const int tile = blockIdx.y - o * tiles;
+    const int t0 = tile * TT;
     if (t0 >= job.nblocks) return;
     const int P = f.P, K = f.K, ring = job.ring;
     const size_t PV = (size_t)(P / NB);                     // vectors per spectrum row
     const int bv = blockIdx.x * blockDim.x + threadIdx.x;   // this thread's vector within a row
-    V acc[TT];
+    // Even time tiles walk the partitions up (j = 0 .. K-1: the window takes ever older blocks), odd
+    // tiles DOWN from the oldest partition (the window takes ever newer blocks).  Neighbouring tiles
+    // share all but TT of their K-1+TT input rows; walking them in opposite directions halves the
+    // distance in time between the two reads of a shared row, so more of the second reads still
+    // find it in the XCD's L2.  Both directions are ONE instruction stream: walking down, the
+    // window and the accumulators are simply held in mirrored order (slot q <-> TT-1-q).
+    const bool down = (tile & 1) != 0;
+    const int first = down ? t0 - (K - 1) : t0;             // first block of the initial window
+    const int xdir = down ? 1 : -1;                         // ring direction of the block entering next
+    const ptrdiff_t hstep = down ? -(ptrdiff_t)PV : (ptrdiff_t)PV;
+    V acc[TT];                                              // acc[a]: output block t0 + (down ? TT-1-a : a)
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) vzero(acc[tt]);
+    for (int a = 0; a < TT; ++a) vzero(acc[a]);
 
     const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
     for (int pe = pe0; pe < pe1; ++pe) {
@@ -724,59 +748,62 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
         const V* __restrict__ X = reinterpret_cast<const V*>(job.fdl + (size_t)pth.in_ch * ring * P) + bv;
         const uint64_t mlo = f.mask[pth.data * 4 + 0];
         const uint64_t mhi = f.mask[pth.data * 4 + 1], mtop = f.mask[pth.data * 4 + 2];
-        V xw[TT];                                           // slot q holds X(t0 + q') with q' == q (mod TT)
+        V xw[TT];                                           // slot q: the block at distance d from `first`, d == (down ? TT-1-q : q) (mod TT)
 #pragma unroll
-        for (int q = 0; q < TT; ++q) xw[q] = vload(X + (size_t)ring_slot(job.slot0, t0 + q, ring) * PV);
-        // software pipeline, D steps deep: the H and X elements of step j+D are
-        // requested at step j (keeps >= 40 KB per CU in flight at 2-4 waves/SIMD)
+        for (int q = 0; q < TT; ++q)
+            xw[q] = vload(X + (size_t)ring_slot(job.slot0, first + (down ? TT - 1 - q : q), ring) * PV);
+        // software pipeline, D steps deep: the H and X elements of step i+D are
+        // requested at step i (keeps >= 40 KB per CU in flight at 2-4 waves/SIMD)
         static_assert(TT % D == 0, "prefetch ring must divide the unroll");
         V hq[D], xq[D];
-        // Row cursors advance by one row per step (no per-step modulo / multiply): the H row
-        // pointer moves forward, the X ring slot moves backward with wrap-around.
-        int xs = ring_slot(job.slot0, t0 - 1, ring);          // ring slot of X(t0 - 1 - d)
-        const V* hp = Hd;
+        // Row cursors advance by one row per step (no per-step modulo / multiply).
+        int xs = ring_slot(job.slot0, down ? first + TT : t0 - 1, ring);   // ring slot of the block entering next
+        const V* hp = down ? Hd + (size_t)(K - 1) * PV : Hd;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (d < K) {
                 hq[d] = vload(hp);
                 xq[d] = vload(X + (size_t)xs * PV);
-                hp += PV;
-                xs = (xs == 0) ? ring - 1 : xs - 1;
+                hp += hstep;
+                xs += xdir;
+                xs = (xs < 0) ? xs + ring : (xs >= ring) ? xs - ring : xs;
             }
         }
-        for (int j0 = 0; j0 < K; j0 += TT) {
+        for (int i0 = 0; i0 < K; i0 += TT) {
 #pragma unroll
-            for (int jj = 0; jj < TT; ++jj) {
-                const int j = j0 + jj;
-                if (j < K) {
-                    const V h = hq[jj % D];
-                    const V xnew = xq[jj % D];
-                    if (j + D < K) {
-                        hq[jj % D] = vload(hp);
-                        xq[jj % D] = vload(X + (size_t)xs * PV);
-                        hp += PV;
-                        xs = (xs == 0) ? ring - 1 : xs - 1;
+            for (int ii = 0; ii < TT; ++ii) {
+                const int i = i0 + ii;                      // step; partition j = i (up) or K-1-i (down)
+                if (i < K) {
+                    const V h = hq[ii % D];
+                    const V xnew = xq[ii % D];
+                    if (i + D < K) {
+                        hq[ii % D] = vload(hp);
+                        xq[ii % D] = vload(X + (size_t)xs * PV);
+                        hp += hstep;
+                        xs += xdir;
+                        xs = (xs < 0) ? xs + ring : (xs >= ring) ? xs - ring : xs;
                     }
-                    const bool on = mask_bit(mlo, mhi, mtop, j);
+                    const bool on = mask_bit(mlo, mhi, mtop, down ? K - 1 - i : i);
                     if (on) {
 #pragma unroll
-                        for (int tt = 0; tt < TT; ++tt) cmacv(acc[tt], xw[(tt - jj) & (TT - 1)], h);
+                        for (int a = 0; a < TT; ++a) cmacv(acc[a], xw[(a - ii) & (TT - 1)], h);
                     }
-                    xw[(TT - 1 - jj) & (TT - 1)] = xnew;    // X(t0 - j - 1): needed from step j+1 on
+                    xw[(TT - 1 - ii) & (TT - 1)] = xnew;    // replaces the block that has just left the window
                 }
             }
         }
     }
     const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * job.nblocks + t0;
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
+    for (int a = 0; a < TT; ++a) {
+        const int tt = down ? TT - 1 - a : a;
         if (t0 + tt < job.nblocks) {
             float2* row = Y + (yrow0 + tt) * P;
             if constexpr (NB == 2) {
-                if (bv == 0) row[1] = float2{acc[tt].z, acc[tt].w};   // bin 0 is packed: written below
-                else reinterpret_cast<float4*>(row)[bv] = acc[tt];
+                if (bv == 0) row[1] = float2{acc[a].z, acc[a].w};   // bin 0 is packed: written below
+                else reinterpret_cast<float4*>(row)[bv] = acc[a];
             } else {
-                if (bv != 0) gst_v2(row + bv, acc[tt]);
+                if (bv != 0) gst_v2(row + bv, acc[a]);
             }
         }
     }

@@ -6,7 +6,7 @@ each phase; this prints the shares.  The product library carries none of this.
 """
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["FOLVE_AMD_LIB"] = os.path.join(ROOT, "folve_amd", "libfolve_amd_trace.so")
+os.environ.setdefault("FOLVE_AMD_LIB", os.path.join(ROOT, "folve_amd", "libfolve_amd_trace.so"))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
