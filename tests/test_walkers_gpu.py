@@ -24,6 +24,7 @@ def _rms(a):
     (1, 3000, 20, 16),      # P = 4096 mono
     (2, 1500, 32, 12),      # P = 2048: forward_dual<11>
     (1, 2000, 16, 20),      # P = 2048 mono
+    (2, 262144, 11, 24),    # cfg3 shape, K = 32: two time tiles, the downward-walking one half full
 ])
 def test_large_batches_match_oracle_and_general_kernels(engine, oracle, channels, size, nstreams, nblocks):
     rng = np.random.default_rng(size + channels)
