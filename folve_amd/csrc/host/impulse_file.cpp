@@ -1,5 +1,6 @@
 #include "impulse_file.h"
 
+#include <math.h>
 #include <string.h>
 
 #include <vector>
@@ -9,6 +10,18 @@ namespace folve {
 namespace {
 uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
 uint16_t le16(const unsigned char* p) { return static_cast<uint16_t>(p[0] | (p[1] << 8)); }
+uint32_t be32(const unsigned char* p) { return p[3] | (p[2] << 8) | (p[1] << 16) | (static_cast<uint32_t>(p[0]) << 24); }
+uint16_t be16(const unsigned char* p) { return static_cast<uint16_t>(p[1] | (p[0] << 8)); }
+uint64_t be64(const unsigned char* p) { return (static_cast<uint64_t>(be32(p)) << 32) | be32(p + 4); }
+// 80-bit IEEE 754 extended (AIFF sample rate)
+double ext80(const unsigned char* p) {
+    const int sign = p[0] >> 7;
+    const int exp = ((p[0] & 0x7f) << 8) | p[1];
+    const uint64_t mant = be64(p + 2);
+    if (exp == 0 && mant == 0) return 0.0;
+    const double v = ldexp(static_cast<double>(mant), exp - 16383 - 63);
+    return sign ? -v : v;
+}
 }  // namespace
 
 ImpulseFile::ImpulseFile() : f_(nullptr) { reset(); }
@@ -19,6 +32,7 @@ void ImpulseFile::reset() {
     rate_ = chan_ = 0;
     form_ = FORM_OTHER;
     bytes_per_sample_ = block_align_ = 0;
+    big_endian_ = signed8_ = false;
     size_ = pos_ = 0;
     data_offset_ = 0;
 }
@@ -35,20 +49,66 @@ int ImpulseFile::open_read(const char* name) {
     FILE* f = fopen(name, "rb");
     if (!f) return ERR_OPEN;
     unsigned char hdr[12];
-    if (fread(hdr, 1, 12, f) != 12 || memcmp(hdr, "RIFF", 4) != 0 || memcmp(hdr + 8, "WAVE", 4) != 0) {
-        fclose(f);
-        return ERR_TYPE;
+    int rc = ERR_TYPE;
+    if (fread(hdr, 1, 12, f) == 12) {
+        if (memcmp(hdr, "RIFF", 4) == 0 && memcmp(hdr + 8, "WAVE", 4) == 0) rc = open_wave(f);
+        else if (memcmp(hdr, "FORM", 4) == 0 && memcmp(hdr + 8, "AIFF", 4) == 0) rc = open_aiff(f, false);
+        else if (memcmp(hdr, "FORM", 4) == 0 && memcmp(hdr + 8, "AIFC", 4) == 0) rc = open_aiff(f, true);
+        else if (memcmp(hdr, "caff", 4) == 0) rc = (fseek(f, 8, SEEK_SET) == 0) ? open_caf(f) : ERR_DATA;
     }
+    if (rc != ERR_NONE) {
+        fclose(f);
+        reset();
+    }
+    return rc;
+}
+
+// The stream is positioned at the first sample.  data_bytes: what the header claims.
+int ImpulseFile::finish_open(FILE* f, int bits, bool is_float, uint64_t data_bytes) {
+    if (chan_ < 1 || rate_ < 0) return ERR_DATA;
+    bytes_per_sample_ = bits / 8;
+    if (!is_float) {
+        switch (bytes_per_sample_) {
+            case 1: form_ = FORM_8BIT; break;
+            case 2: form_ = FORM_16BIT; break;
+            case 3: form_ = FORM_24BIT; break;
+            case 4: form_ = FORM_32BIT; break;
+            default: return ERR_FORM;
+        }
+    } else if (bytes_per_sample_ == 4) {
+        form_ = FORM_FLOAT;
+    } else if (bytes_per_sample_ == 8) {
+        form_ = FORM_DOUBLE;
+    } else {
+        return ERR_FORM;
+    }
+    if (bits != bytes_per_sample_ * 8) return ERR_FORM;
+    if (block_align_ == 0) block_align_ = bytes_per_sample_ * chan_;
+    if (block_align_ != bytes_per_sample_ * chan_) return ERR_FORM;
+    data_offset_ = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const long avail = ftell(f) - data_offset_;
+    fseek(f, data_offset_, SEEK_SET);
+    uint64_t bytes = data_bytes;
+    if (avail >= 0 && bytes > static_cast<uint64_t>(avail)) bytes = static_cast<uint64_t>(avail);
+    const uint64_t frames = bytes / static_cast<uint64_t>(block_align_);
+    size_ = frames > 0xffffffffu ? 0xffffffffu : static_cast<uint32_t>(frames);
+    pos_ = 0;
+    f_ = f;
+    return ERR_NONE;
+}
+
+int ImpulseFile::open_wave(FILE* f) {
     int tag = 0, bits = 0;
     bool have_fmt = false;
     for (;;) {
         unsigned char ck[8];
-        if (fread(ck, 1, 8, f) != 8) { fclose(f); return ERR_DATA; }
+        if (fread(ck, 1, 8, f) != 8) return ERR_DATA;
         const uint32_t len = le32(ck + 4);
         if (memcmp(ck, "fmt ", 4) == 0) {
             unsigned char b[40];
             const uint32_t n = len < sizeof(b) ? len : static_cast<uint32_t>(sizeof(b));
-            if (len < 16 || fread(b, 1, n, f) != n) { fclose(f); return ERR_DATA; }
+            if (len < 16 || fread(b, 1, n, f) != n) return ERR_DATA;
             tag = le16(b);
             chan_ = le16(b + 2);
             rate_ = static_cast<int>(le32(b + 4));
@@ -59,37 +119,98 @@ int ImpulseFile::open_read(const char* name) {
             if (skip) fseek(f, skip, SEEK_CUR);
             have_fmt = true;
         } else if (memcmp(ck, "data", 4) == 0) {
-            if (!have_fmt || chan_ < 1 || block_align_ < 1) { fclose(f); return ERR_DATA; }
-            bytes_per_sample_ = bits / 8;
-            if (tag == 1) {
-                switch (bytes_per_sample_) {
-                    case 1: form_ = FORM_8BIT; break;
-                    case 2: form_ = FORM_16BIT; break;
-                    case 3: form_ = FORM_24BIT; break;
-                    case 4: form_ = FORM_32BIT; break;
-                    default: fclose(f); return ERR_FORM;
-                }
-            } else if (tag == 3 && bytes_per_sample_ == 4) {
-                form_ = FORM_FLOAT;
-            } else if (tag == 3 && bytes_per_sample_ == 8) {
-                form_ = FORM_DOUBLE;
-            } else {
-                fclose(f);
-                return ERR_FORM;
-            }
-            if (block_align_ != bytes_per_sample_ * chan_) { fclose(f); return ERR_FORM; }
-            data_offset_ = ftell(f);
-            fseek(f, 0, SEEK_END);
-            const long avail = ftell(f) - data_offset_;
-            fseek(f, data_offset_, SEEK_SET);
-            uint32_t bytes = len;
-            if (avail >= 0 && static_cast<long>(bytes) > avail) bytes = static_cast<uint32_t>(avail);
-            size_ = bytes / static_cast<uint32_t>(block_align_);
-            pos_ = 0;
-            f_ = f;
-            return ERR_NONE;
+            if (!have_fmt || block_align_ < 1) return ERR_DATA;
+            if (tag != 1 && tag != 3) return ERR_FORM;
+            return finish_open(f, bits, tag == 3, len);
         } else {
-            if (fseek(f, static_cast<long>(len) + (len & 1), SEEK_CUR) != 0) { fclose(f); return ERR_DATA; }
+            if (fseek(f, static_cast<long>(len) + (len & 1), SEEK_CUR) != 0) return ERR_DATA;
+        }
+    }
+}
+
+// AIFF / AIFF-C: big-endian chunks; COMM = channels, frames, bits, 80-bit rate [, compression id]
+int ImpulseFile::open_aiff(FILE* f, bool aifc) {
+    int bits = 0;
+    uint32_t frames = 0;
+    bool have_comm = false, is_float = false;
+    big_endian_ = true;
+    signed8_ = true;
+    for (;;) {
+        unsigned char ck[8];
+        if (fread(ck, 1, 8, f) != 8) return ERR_DATA;
+        const uint32_t len = be32(ck + 4);
+        if (memcmp(ck, "COMM", 4) == 0) {
+            unsigned char b[22];
+            const uint32_t need = aifc ? 22 : 18;
+            if (len < need || fread(b, 1, need, f) != need) return ERR_DATA;
+            chan_ = be16(b);
+            frames = be32(b + 2);
+            bits = be16(b + 6);
+            rate_ = static_cast<int>(ext80(b + 8) + 0.5);
+            if (aifc) {
+                const unsigned char* id = b + 18;
+                if (memcmp(id, "NONE", 4) == 0 || memcmp(id, "twos", 4) == 0) {
+                } else if (memcmp(id, "sowt", 4) == 0) {
+                    big_endian_ = false;
+                } else if (memcmp(id, "fl32", 4) == 0 || memcmp(id, "FL32", 4) == 0) {
+                    is_float = true; bits = 32;
+                } else if (memcmp(id, "fl64", 4) == 0 || memcmp(id, "FL64", 4) == 0) {
+                    is_float = true; bits = 64;
+                } else {
+                    return ERR_FORM;                                // a compressed AIFF-C
+                }
+            }
+            bits = (bits + 7) / 8 * 8;                              // AIFF stores e.g. 20-bit samples in 3 bytes
+            const long skip = static_cast<long>(len - need) + (len & 1);
+            if (skip) fseek(f, skip, SEEK_CUR);
+            have_comm = true;
+        } else if (memcmp(ck, "SSND", 4) == 0) {
+            unsigned char b[8];
+            if (!have_comm || len < 8 || fread(b, 1, 8, f) != 8) return ERR_DATA;   // COMM after SSND: not handled
+            const uint32_t offset = be32(b);
+            if (offset && fseek(f, static_cast<long>(offset), SEEK_CUR) != 0) return ERR_DATA;
+            const uint64_t claimed = static_cast<uint64_t>(frames) * static_cast<uint64_t>(chan_) * (bits / 8);
+            const uint64_t in_chunk = static_cast<uint64_t>(len) - 8 - offset;
+            return finish_open(f, bits, is_float, claimed < in_chunk ? claimed : in_chunk);
+        } else {
+            if (fseek(f, static_cast<long>(len) + (len & 1), SEEK_CUR) != 0) return ERR_DATA;
+        }
+    }
+}
+
+// Core Audio Format: chunks of (type, int64 size); 'desc' = f64 rate, format id, flags, bytes/packet,
+// frames/packet, channels, bits; 'data' = uint32 edit count + samples (size -1: to the end of the file)
+int ImpulseFile::open_caf(FILE* f) {
+    int bits = 0;
+    bool have_desc = false, is_float = false;
+    signed8_ = true;
+    for (;;) {
+        unsigned char ck[12];
+        if (fread(ck, 1, 12, f) != 12) return ERR_DATA;
+        const int64_t len = static_cast<int64_t>(be64(ck + 4));
+        if (memcmp(ck, "desc", 4) == 0) {
+            unsigned char b[32];
+            if (len < 32 || fread(b, 1, 32, f) != 32) return ERR_DATA;
+            const uint64_t rb = be64(b);
+            double r; memcpy(&r, &rb, 8);
+            rate_ = static_cast<int>(r + 0.5);
+            if (memcmp(b + 8, "lpcm", 4) != 0) return ERR_FORM;
+            const uint32_t flags = be32(b + 12);
+            is_float = (flags & 1) != 0;
+            big_endian_ = (flags & 2) == 0;
+            block_align_ = static_cast<int>(be32(b + 16));
+            if (be32(b + 20) != 1) return ERR_FORM;                 // frames per packet
+            chan_ = static_cast<int>(be32(b + 24));
+            bits = static_cast<int>(be32(b + 28));
+            if (len > 32) fseek(f, static_cast<long>(len - 32), SEEK_CUR);
+            have_desc = true;
+        } else if (memcmp(ck, "data", 4) == 0) {
+            unsigned char edit[4];
+            if (!have_desc || fread(edit, 1, 4, f) != 4) return ERR_DATA;
+            const uint64_t bytes = len < 0 ? ~static_cast<uint64_t>(0) : static_cast<uint64_t>(len - 4);
+            return finish_open(f, bits, is_float, bytes);
+        } else {
+            if (len < 0 || fseek(f, static_cast<long>(len), SEEK_CUR) != 0) return ERR_DATA;
         }
     }
 }
@@ -110,11 +231,17 @@ int ImpulseFile::read(float* data, uint32_t frames) {
     const size_t got = fread(raw.data(), static_cast<size_t>(block_align_), frames, f_);
     pos_ += static_cast<uint32_t>(got);
     const size_t n = got * static_cast<size_t>(chan_);
-    const unsigned char* p = raw.data();
+    unsigned char* p = raw.data();
     for (size_t i = 0; i < n; ++i, p += bytes_per_sample_) {
+        if (big_endian_) {                                          // to little-endian, in place
+            for (int a = 0, b = bytes_per_sample_ - 1; a < b; ++a, --b) { const unsigned char t = p[a]; p[a] = p[b]; p[b] = t; }
+        }
         float v = 0.0f;
         switch (form_) {
-            case FORM_8BIT: v = static_cast<float>(static_cast<int>(p[0]) - 128) / 128.0f; break;
+            case FORM_8BIT:
+                v = signed8_ ? static_cast<float>(static_cast<signed char>(p[0])) / 128.0f
+                             : static_cast<float>(static_cast<int>(p[0]) - 128) / 128.0f;
+                break;
             case FORM_16BIT: v = static_cast<float>(static_cast<int16_t>(le16(p))) / 32768.0f; break;
             case FORM_24BIT: {
                 const int32_t s = static_cast<int32_t>((static_cast<uint32_t>(p[0]) << 8) | (static_cast<uint32_t>(p[1]) << 16) |

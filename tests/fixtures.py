@@ -35,6 +35,74 @@ def write_wav(path, data, rate=44100, fmt="pcm16"):
         f.write(hdr + raw)
 
 
+def _ext80(x):
+    """IEEE 754 80-bit extended, big-endian (the AIFF sample-rate field)."""
+    import math
+    if x == 0:
+        return b"\0" * 10
+    m, e = math.frexp(x)                                   # x = m * 2**e, 0.5 <= m < 1
+    return struct.pack(">HQ", e - 1 + 16383, int(m * (1 << 64)))
+
+
+def write_aiff(path, data, rate=44100, fmt="pcm16"):
+    """AIFF (pcm8/pcm16/pcm24/pcm32, big-endian) or AIFF-C (sowt16 = little-endian PCM, fl32).  data: float [frames, ch]."""
+    data = np.asarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    frames, ch = data.shape
+    comp = None
+    if fmt == "pcm8":
+        raw, bits = np.clip(np.round(data * 128.0), -128, 127).astype(np.int8).tobytes(), 8
+    elif fmt == "pcm16":
+        raw, bits = np.clip(np.round(data * 32768.0), -32768, 32767).astype(">i2").tobytes(), 16
+    elif fmt == "pcm24":
+        v = np.clip(np.round(data * 8388608.0), -8388608, 8388607).astype(">i4")
+        raw, bits = v.view(np.uint8).reshape(-1, 4)[:, 1:].tobytes(), 24
+    elif fmt == "pcm32":
+        raw, bits = np.clip(np.round(data * 2147483648.0), -2**31, 2**31 - 1).astype(">i4").tobytes(), 32
+    elif fmt == "sowt16":
+        raw, bits, comp = np.clip(np.round(data * 32768.0), -32768, 32767).astype("<i2").tobytes(), 16, b"sowt"
+    elif fmt == "fl32":
+        raw, bits, comp = data.astype(">f4").tobytes(), 32, b"fl32"
+    else:
+        raise ValueError(fmt)
+    comm = struct.pack(">hIh", ch, frames, bits) + _ext80(float(rate))
+    if comp:
+        comm += comp + b"\x00\x00"                          # empty pascal string + pad
+    chunks = b"COMM" + struct.pack(">I", len(comm)) + comm
+    chunks += b"ANNO" + struct.pack(">I", 3) + b"abc\0"    # an odd-sized chunk before the samples
+    chunks += b"SSND" + struct.pack(">III", len(raw) + 8, 0, 0) + raw + (b"\0" if len(raw) & 1 else b"")
+    with open(path, "wb") as f:
+        f.write(b"FORM" + struct.pack(">I", 4 + len(chunks)) + (b"AIFC" if comp else b"AIFF") + chunks)
+
+
+def write_caf(path, data, rate=44100, fmt="f32le", open_ended=False):
+    """Core Audio Format, linear PCM: f32le, f32be, i16be, i24le, i8.  data: float [frames, ch]."""
+    data = np.asarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    ch = data.shape[1]
+    if fmt == "f32le":
+        raw, flags, bits = data.astype("<f4").tobytes(), 3, 32
+    elif fmt == "f32be":
+        raw, flags, bits = data.astype(">f4").tobytes(), 1, 32
+    elif fmt == "i16be":
+        raw, flags, bits = np.clip(np.round(data * 32768.0), -32768, 32767).astype(">i2").tobytes(), 0, 16
+    elif fmt == "i24le":
+        v = np.clip(np.round(data * 8388608.0), -8388608, 8388607).astype("<i4")
+        raw, flags, bits = v.view(np.uint8).reshape(-1, 4)[:, :3].tobytes(), 2, 24
+    elif fmt == "i8":
+        raw, flags, bits = np.clip(np.round(data * 128.0), -128, 127).astype(np.int8).tobytes(), 0, 8
+    else:
+        raise ValueError(fmt)
+    desc = struct.pack(">d4sIIIII", float(rate), b"lpcm", flags, ch * bits // 8, 1, ch, bits)
+    body = b"desc" + struct.pack(">q", len(desc)) + desc
+    body += b"free" + struct.pack(">q", 5) + b"\0" * 5       # CAF chunks are not padded
+    body += b"data" + struct.pack(">q", -1 if open_ended else len(raw) + 4) + struct.pack(">I", 0) + raw
+    with open(path, "wb") as f:
+        f.write(b"caff" + struct.pack(">HH", 1, 0) + body)
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, "demo_%s.npz" % name))
 

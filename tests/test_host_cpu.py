@@ -224,6 +224,52 @@ def test_loader_hilbert_copy_cd_quoting_and_formats(tmp_path, oracle):
     assert np.abs(y[:16000, 2] - h23).max() < 1e-6
 
 
+def test_loader_reads_aiff_and_caf_impulse_files(tmp_path):
+    """zita-audiofile.cc:63-75 takes whatever libsndfile opens and names CAF and WAVEX; the loader
+    reads the uncompressed AIFF / AIFF-C / CAF forms itself, normalised as sf_readf_float does."""
+    from fixtures import write_aiff, write_caf
+    rng = np.random.default_rng(9)
+    ir = rng.uniform(-0.9, 0.9, (777, 2))
+    d = str(tmp_path)
+    files = []
+    for fmt in ("pcm8", "pcm16", "pcm24", "pcm32", "sowt16", "fl32"):
+        write_aiff(os.path.join(d, "a_%s.aif" % fmt), ir, 48000, fmt)
+        files.append(("a_%s.aif" % fmt, fmt))
+    for fmt in ("f32le", "f32be", "i16be", "i24le", "i8"):
+        write_caf(os.path.join(d, "c_%s.caf" % fmt), ir, 44100, fmt, open_ended=(fmt == "i16be"))
+        files.append(("c_%s.caf" % fmt, fmt))
+    text = "/convolver/new 1 %d 512 1000\n" % len(files)
+    for k, (name, _) in enumerate(files):
+        text += "/impulse/read 1 %d 1.0 %d 5 0 2 %s\n" % (k + 1, k, name)      # offset 5, second channel, delay k
+    st, flt, z = H.config_load(_conf(tmp_path, text))
+    assert st == 0 and z["nout"] == len(files)
+
+    def q(scale, lo, hi):
+        return np.clip(np.round(ir * scale), lo, hi).astype(np.int64)
+    expect = {
+        "pcm8": q(128.0, -128, 127).astype(np.float32) / np.float32(128.0),
+        "i8": q(128.0, -128, 127).astype(np.float32) / np.float32(128.0),
+        "pcm16": q(32768.0, -32768, 32767).astype(np.float32) / np.float32(32768.0),
+        "sowt16": q(32768.0, -32768, 32767).astype(np.float32) / np.float32(32768.0),
+        "i16be": q(32768.0, -32768, 32767).astype(np.float32) / np.float32(32768.0),
+        "pcm24": (q(8388608.0, -8388608, 8388607) * 256).astype(np.float32) / np.float32(2147483648.0),
+        "i24le": (q(8388608.0, -8388608, 8388607) * 256).astype(np.float32) / np.float32(2147483648.0),
+        "pcm32": q(2147483648.0, -2**31, 2**31 - 1).astype(np.float32) / np.float32(2147483648.0),
+        "fl32": ir.astype(np.float32), "f32le": ir.astype(np.float32), "f32be": ir.astype(np.float32),
+    }
+    for k, (name, fmt) in enumerate(files):
+        h = np.zeros(1000, np.float32)
+        h[k:k + 772] = expect[fmt][5:, 1]
+        assert np.array_equal(flt.taps(0, k, 1000), h), name
+    # a compressed AIFF-C and a truncated header are refused (ERR_OTHER from readfile is swallowed: no path)
+    open(os.path.join(d, "bad.aifc"), "wb").write(b"FORM\0\0\0\x1eAIFCCOMM\0\0\0\x16" + b"\0\1\0\0\0\1\0\x10"
+                                                   + b"\x40\x0e\xac\x44\0\0\0\0\0\0" + b"ima4")
+    open(os.path.join(d, "short.caf"), "wb").write(b"caff\0\1\0\0desc")
+    for bad in ("bad.aifc", "short.caf"):
+        st, flt, _ = H.config_load(_conf(tmp_path, "/convolver/new 1 1 512 1000\n/impulse/read 1 1 1 0 0 0 1 %s\n" % bad))
+        assert st != 0 or flt.path_partitions(0, 0) == 0, bad
+
+
 def test_pool_path_choice_and_error_strings(tmp_path):
     d = make_echo_filter_dir(tmp_path)
     pool = H.ProcessorPool(3)
