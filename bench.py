@@ -41,8 +41,8 @@ def alg_bytes(P, K_eff, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=32, help="consecutive blocks per stream per step")
     ap.add_argument("--taps", type=int, default=262144)
