@@ -38,7 +38,11 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     for row in csv.DictReader(open(f)):
         n = short(row["Kernel_Name"])
         if n:
-            acc["%s grid=%s" % (n, row.get("Grid_Size", "?"))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            if "Grid_Size" in row:
+                grid = row["Grid_Size"]
+            else:                                            # kernel-trace csv: per-dimension thread counts
+                grid = str(int(row.get("Grid_Size_X", 1)) * int(row.get("Grid_Size_Y", 1)) * int(row.get("Grid_Size_Z", 1)))
+            acc["%s grid=%s" % (n, grid)].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     for k, v in acc.items():
         res["kernel_trace"][k] = {"dispatches": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
