@@ -55,6 +55,8 @@ struct DevTmp {
 
 struct TableOffsets { int o[4]; int total; };
 
+constexpr int kMaxChunks = 8;     // measured on cfg3: 2 chunks 4.9 ms, 4: 4.2, 8: 3.9, 16: 8.9 (launches too small)
+
 struct fe_engine {
     std::atomic<int> refs{1};     // creator + one per live filter (streams hold their filter)
     int device = 0;
@@ -87,6 +89,11 @@ struct fe_engine {
     size_t stage_in_bytes = 0;
     float* stage_out = nullptr;
     size_t stage_out_bytes = 0;
+    // Large host-pointer batches are cut into chunks of whole streams and pipelined over three
+    // HIP streams: chunk c+1 rides the bus in while chunk c computes and chunk c-1 rides out
+    // (PCIe is full duplex; a serial H2D - compute - D2H uses one direction at a time).
+    hipStream_t cp_in = nullptr, cp_out = nullptr;
+    hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     // profiling
     bool profiling = false;
     hipEvent_t pev[4] = {};
@@ -272,52 +279,16 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     return FE_OK;
 }
 
-// peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
-int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
-                   const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr) {
-    const bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
-    const bool async = device_ptrs && (flags & FE_ASYNC);
-    HIP_TRY(hipSetDevice(e->device));
-
-    std::vector<Item> all((size_t)n);
-    size_t in_floats = 0, out_floats = 0;
-    for (int i = 0; i < n; ++i) {
-        fe_stream* s = streams[i];
-        if (!s || s->eng != e) return fail(FE_ERR_PARAM, "stream %d is null or on another engine", i);
-        if (nframes[i] < 0) return fail(FE_ERR_PARAM, "negative frame count");
-        if (nframes[i] > 0 && (!in[i] || !out[i])) return fail(FE_ERR_PARAM, "null buffer for stream %d", i);
-        for (int k = 0; k < i; ++k)
-            if (streams[k] == s) return fail(FE_ERR_PARAM, "stream listed twice in one batch");
-        all[(size_t)i] = Item{s, in[i], out[i], nframes[i]};
-        // staging offsets stay 16-byte aligned so that every stream takes the same kernel path
-        // as it would alone (a batch is bit-identical to its streams run one by one)
-        in_floats += ((size_t)nframes[i] * s->f->ninp + 3) & ~(size_t)3;
-        out_floats += ((size_t)nframes[i] * s->f->nout + 3) & ~(size_t)3;
-    }
-    if (!device_ptrs) {
-        int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
-        if (rc) return rc;
-        rc = ensure_bytes(e, (void**)&e->stage_out, &e->stage_out_bytes, out_floats * sizeof(float));
-        if (rc) return rc;
-        size_t io = 0, oo = 0;
-        for (int i = 0; i < n; ++i) {
-            const size_t ni = (size_t)nframes[i] * streams[i]->f->ninp, no = (size_t)nframes[i] * streams[i]->f->nout;
-            if (ni) HIP_TRY(hipMemcpyAsync(e->stage_in + io, in[i], ni * sizeof(float), hipMemcpyHostToDevice, e->stream));
-            all[(size_t)i].in = e->stage_in + io;
-            all[(size_t)i].out = e->stage_out + oo;
-            io += (ni + 3) & ~(size_t)3;
-            oo += (no + 3) & ~(size_t)3;
-        }
-    }
-    // group by filter; each group runs launch rounds until its frames are consumed
-    std::vector<char> done((size_t)n, 0);
-    for (int i = 0; i < n; ++i) {
-        if (done[(size_t)i]) continue;
+// Launch rounds for streams [i0, i1) of a call, grouped by filter; each group runs until its
+// frames are consumed.
+int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int i0, int i1) {
+    std::vector<char> done((size_t)(i1 - i0), 0);
+    for (int i = i0; i < i1; ++i) {
+        if (done[(size_t)(i - i0)]) continue;
         fe_filter* f = streams[i]->f;
         std::vector<Item> group;
-        std::vector<int> idx;
-        for (int k = i; k < n; ++k)
-            if (!done[(size_t)k] && streams[k]->f == f) { group.push_back(all[(size_t)k]); idx.push_back(k); done[(size_t)k] = 1; }
+        for (int k = i; k < i1; ++k)
+            if (!done[(size_t)(k - i0)] && streams[k]->f == f) { group.push_back(all[(size_t)k]); done[(size_t)(k - i0)] = 1; }
         long long units = 0;
         for (const Item& it : group) units += (it.left + f->P - 1) / f->P * f->nout;
         const bool split = !e->profiling && e->max_lanes > 1 && group.size() >= 2 && units >= e->split_min_units;
@@ -348,12 +319,132 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         HIP_TRY(hipEventRecord(e->join_ev, e->lanes[1].st));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
     }
-    if (!device_ptrs) {
-        size_t oo = 0;
-        for (int i = 0; i < n; ++i) {
+    return FE_OK;
+}
+
+// A host-pointer call as a three-stage pipeline over chunks of whole streams (see fe_engine).
+// all[i].in / .out already point into the staging buffers.
+int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* const* in, float* const* out,
+                  const long long* nframes, std::vector<Item>& all) {
+    if (!e->cp_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->cp_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->cp_out, hipStreamNonBlocking));
+        for (int i = 0; i < kMaxChunks; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_k[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    // chunk boundaries: whole streams, about equal frame counts
+    long long total = 0;
+    for (int i = 0; i < n; ++i) total += nframes[i] * (streams[i]->f->ninp + streams[i]->f->nout);
+    const int want = std::max(1, std::min(kMaxChunks, n / 2));
+    int first[kMaxChunks + 1];
+    int chunks = 0;
+    long long acc = 0;
+    first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        acc += nframes[i] * (streams[i]->f->ninp + streams[i]->f->nout);
+        if (chunks + 1 < want && acc * want >= total * (chunks + 1) && i + 1 < n) first[++chunks] = i + 1;
+    }
+    first[++chunks] = n;
+
+    std::vector<const float*> dev_out((size_t)n);
+    for (int i = 0; i < n; ++i) dev_out[(size_t)i] = all[(size_t)i].out;   // launch rounds advance Item::out
+    auto copy_in = [&](int c) -> int {
+        for (int i = first[c]; i < first[c + 1]; ++i) {
+            const size_t ni = (size_t)nframes[i] * streams[i]->f->ninp;
+            if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, e->cp_in));
+        }
+        HIP_TRY(hipEventRecord(e->ev_in[c], e->cp_in));
+        return FE_OK;
+    };
+    auto copy_out = [&](int c) -> int {
+        HIP_TRY(hipStreamWaitEvent(e->cp_out, e->ev_k[c], 0));
+        for (int i = first[c]; i < first[c + 1]; ++i) {
             const size_t no = (size_t)nframes[i] * streams[i]->f->nout;
-            if (no) HIP_TRY(hipMemcpyAsync(out[i], e->stage_out + oo, no * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            if (no) HIP_TRY(hipMemcpyAsync(out[i], dev_out[(size_t)i], no * sizeof(float), hipMemcpyDeviceToHost, e->cp_out));
+        }
+        return FE_OK;
+    };
+    // the staging buffers may still be read by earlier work on the engine's stream
+    HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->cp_in, e->ev_fork, 0));
+    int rc = copy_in(0);
+    if (rc) return rc;
+    for (int c = 0; c < chunks; ++c) {
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_in[c], 0));
+        rc = run_groups(e, streams, all, first[c], first[c + 1]);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e->ev_k[c], e->stream));
+        if (c + 1 < chunks) { rc = copy_in(c + 1); if (rc) return rc; }
+        rc = copy_out(c);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->ev_join, e->cp_out));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    return FE_OK;
+}
+
+// peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
+int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
+                   const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr) {
+    const bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
+    const bool async = device_ptrs && (flags & FE_ASYNC);
+    HIP_TRY(hipSetDevice(e->device));
+
+    std::vector<Item> all((size_t)n);
+    std::vector<const float*> stage_out_of((size_t)n, nullptr);
+    size_t in_floats = 0, out_floats = 0;
+    for (int i = 0; i < n; ++i) {
+        fe_stream* s = streams[i];
+        if (!s || s->eng != e) return fail(FE_ERR_PARAM, "stream %d is null or on another engine", i);
+        if (nframes[i] < 0) return fail(FE_ERR_PARAM, "negative frame count");
+        if (nframes[i] > 0 && (!in[i] || !out[i])) return fail(FE_ERR_PARAM, "null buffer for stream %d", i);
+        for (int k = 0; k < i; ++k)
+            if (streams[k] == s) return fail(FE_ERR_PARAM, "stream listed twice in one batch");
+        all[(size_t)i] = Item{s, in[i], out[i], nframes[i]};
+        // staging offsets stay 16-byte aligned so that every stream takes the same kernel path
+        // as it would alone (a batch is bit-identical to its streams run one by one)
+        in_floats += ((size_t)nframes[i] * s->f->ninp + 3) & ~(size_t)3;
+        out_floats += ((size_t)nframes[i] * s->f->nout + 3) & ~(size_t)3;
+    }
+    if (!device_ptrs) {
+        int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_bytes(e, (void**)&e->stage_out, &e->stage_out_bytes, out_floats * sizeof(float));
+        if (rc) return rc;
+        size_t io = 0, oo = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t ni = (size_t)nframes[i] * streams[i]->f->ninp, no = (size_t)nframes[i] * streams[i]->f->nout;
+            all[(size_t)i].in = e->stage_in + io;
+            all[(size_t)i].out = e->stage_out + oo;
+            stage_out_of[(size_t)i] = e->stage_out + oo;
+            io += (ni + 3) & ~(size_t)3;
             oo += (no + 3) & ~(size_t)3;
+        }
+    }
+    // worth pipelining: several streams and enough bytes that the bus time dwarfs the extra events
+    const bool pipelined = !device_ptrs && !e->profiling && e->max_lanes == 1 && n >= 4 &&
+                           (in_floats + out_floats) * sizeof(float) >= ((size_t)16 << 20);
+    if (pipelined) {
+        int rc = run_pipelined(e, streams, n, in, out, nframes, all);
+        if (rc) return rc;
+    } else {
+        if (!device_ptrs) {
+            for (int i = 0; i < n; ++i) {
+                const size_t ni = (size_t)nframes[i] * streams[i]->f->ninp;
+                if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            }
+        }
+        int rc = run_groups(e, streams, all, 0, n);
+        if (rc) return rc;
+        if (!device_ptrs) {
+            for (int i = 0; i < n; ++i) {
+                const size_t no = (size_t)nframes[i] * streams[i]->f->nout;
+                if (no) HIP_TRY(hipMemcpyAsync(out[i], stage_out_of[(size_t)i], no * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            }
         }
     }
     if (peaks_out) {
@@ -432,6 +523,14 @@ static void engine_release(fe_engine* e) {
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     if (e->join_ev) (void)hipEventDestroy(e->join_ev);
     if (e->stagger_ev) (void)hipEventDestroy(e->stagger_ev);
+    if (e->cp_in) { (void)hipStreamSynchronize(e->cp_in); (void)hipStreamDestroy(e->cp_in); }
+    if (e->cp_out) { (void)hipStreamSynchronize(e->cp_out); (void)hipStreamDestroy(e->cp_out); }
+    for (int i = 0; i < kMaxChunks; ++i) {
+        if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
+        if (e->ev_k[i]) (void)hipEventDestroy(e->ev_k[i]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     for (int i = 0; i < kJobSlots; ++i) {

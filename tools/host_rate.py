@@ -24,6 +24,19 @@ for _ in range(n):
 dt = (time.perf_counter() - t0) / n
 print("host-pointer batch: %.2f ms/step, %.1f Msamples/s (pageable host memory, H2D + K1-K3 + D2H)" % (dt * 1e3, S * T * P * 2 / dt / 1e6))
 
+# the same with page-locked caller buffers
+import torch
+xp = [torch.from_numpy(x).pin_memory() for x in xs]
+yp = [torch.zeros(T * P, 2).pin_memory() for _ in xs]
+planp = BatchPlan(streams, [x.data_ptr() for x in xp], [y.data_ptr() for y in yp], [T * P] * S, FE_HOST_PTRS)
+for _ in range(2):
+    planp.run()
+t0 = time.perf_counter()
+for _ in range(n):
+    planp.run()
+dt = (time.perf_counter() - t0) / n
+print("host-pointer batch: %.2f ms/step, %.1f Msamples/s (page-locked host memory)" % (dt * 1e3, S * T * P * 2 / dt / 1e6))
+
 # one block per call through the exact SoundProcessor::Process path (host pointers, synchronous, peaks fetched)
 st = flt.open_stream(1)
 x = xs[0][:P]
