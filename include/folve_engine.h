@@ -117,7 +117,9 @@ long long fe_stream_blocks_done(const fe_stream *s);
 /* ---- batch: many independent streams in one launch ------------------------ */
 /* streams[i] consumes nframes[i] interleaved frames from in[i] and produces as
  * many into out[i].  All streams must live on one engine; streams of different
- * filters are launched in groups.  flags: FE_HOST_PTRS or FE_DEVICE_PTRS[|FE_ASYNC]. */
+ * filters are launched in groups.  flags: FE_HOST_PTRS or FE_DEVICE_PTRS[|FE_ASYNC].
+ * Large host-pointer batches are pipelined (copy in / compute / copy out overlap); page-locked
+ * buffers (hipHostMalloc, hipHostRegister) let both bus directions run at once. */
 int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
                      float *const *out, int flags);
 
