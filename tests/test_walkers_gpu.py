@@ -120,3 +120,49 @@ def test_two_lane_fork_matches_single_lane(oracle):
     b1, b2 = run(2)                     # S * T * 2 = 576 block-channels >= the 512-unit fork threshold
     for x, y in zip(a1 + a2, b1 + b2):
         assert np.abs(x - y).max() <= 2e-6
+
+
+def test_pipelined_host_batch_mixed_filters_and_rounds(engine, oracle):
+    """A host-pointer batch above 16 MB is cut into chunks of streams that ride the bus in, compute
+    and ride out on three HIP streams (engine.cpp run_pipelined).  Streams of two filters interleaved,
+    ragged lengths, more blocks than a launch round carries, page-locked and pageable callers: every
+    stream equals its solo run to rounding and the float64 convolution to the parity bound."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(23)
+    sizes = (20000, 9000)                                              # K = 3 and K = 2 at P = 8192
+    flts, taps = [], []
+    for size in sizes:
+        h = [(rng.standard_normal(size) / np.sqrt(size)).astype(np.float32) for _ in range(2)]
+        f = fa.Filter(engine, 2, 2, size)
+        for c in range(2):
+            f.add(c, c, h[c])
+        f.commit()
+        flts.append(f); taps.append(h)
+    P, S, maxb = 8192, 14, 6
+    lens = [int(20 * P - 1000 * s - (s % 3)) for s in range(S)]        # 20 blocks: four launch rounds of <= 6
+    xs = [rng.uniform(-1, 1, (n, 2)).astype(np.float32) for n in lens]
+    assert sum(x.nbytes for x in xs) * 2 >= 16 << 20
+    which = [s % 2 for s in range(S)]
+    streams = [flts[w].open_stream(maxb) for w in which]
+    ys = fa.batch_process(streams, xs)                                 # pageable numpy buffers
+    pinned = [torch.from_numpy(x).pin_memory() for x in xs]
+    outs = [torch.zeros(n, 2).pin_memory() for n in lens]
+    streams2 = [flts[w].open_stream(maxb) for w in which]
+    from folve_amd.capi import BatchPlan, FE_HOST_PTRS
+    BatchPlan(streams2, [t.data_ptr() for t in pinned], [t.data_ptr() for t in outs], lens, FE_HOST_PTRS).run()
+    for s in range(S):
+        assert np.array_equal(ys[s], outs[s].numpy()), s               # same chunks, same kernels
+    for s in (0, 1, 6, 13):
+        solo = flts[which[s]].open_stream(maxb).process_blocks(xs[s])
+        assert _rms(ys[s] - solo) <= 2e-6
+        hd = {(c, c): taps[which[s]][c] for c in range(2)}
+        y64 = oracle.linear_convolution_f64(xs[s], hd, 2)
+        assert _rms(ys[s] - y64) <= TOL and _rms(ys[s] - y64) / _rms(y64) <= TOL
+    # state carried: a second, small (unpipelined) call continues every stream
+    more = [rng.uniform(-1, 1, (P + 3, 2)).astype(np.float32) for _ in range(S)]
+    ys2 = fa.batch_process(streams, more)
+    s = 5
+    hd = {(c, c): taps[which[s]][c] for c in range(2)}
+    pad = (-lens[s]) % P
+    full = oracle.linear_convolution_f64(np.concatenate([np.pad(xs[s], ((0, pad), (0, 0))), more[s]]), hd, 2)
+    assert _rms(ys2[s] - full[lens[s] + pad:]) <= TOL
