@@ -593,38 +593,49 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     }
 }
 
-// Packed bin 0 = (DC, Nyquist): two real products, not a complex one.  Done by
-// the first TT threads of the workgroup that owns bin 0, one output block each.
+// Packed bin 0 = (DC, Nyquist): two real products, not a complex one.  Done at the end by the
+// whole workgroup that owns bin 0: thread t takes output block t % TT and every (threads / TT)-th
+// partition, so each thread has one to three independent load pairs in flight; the groups are
+// summed through LDS.  (As a serial loop in the workgroup's first wavefront this tail took 7 %
+// of the whole kernel: 14 of 205 us at cfg3.)
 template <int TT>
 __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const FilterDev& f, float2* __restrict__ Y,
                                                 int t0, int pe0, int pe1, size_t yrow0) {
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;         // first wavefront of the workgroup owning bin 0
+    if (blockIdx.x != 0) return;                              // uniform over the workgroup
+    __shared__ float2 part[256];
     const int P = f.P, K = f.K, ring = job.ring;
-    constexpr int G = 64 / TT;                                // lanes per output block (TT <= 32)
-    const int tt = threadIdx.x % TT, g = threadIdx.x / TT;    // this lane: output tt, partitions g, g+G, ...
+    const int G = blockDim.x / TT;                            // partition groups (threads: 64..256, TT <= 32)
+    const int tt = threadIdx.x % TT, g = threadIdx.x / TT;
     float re = 0.f, im = 0.f;
-    for (int pe = pe0; pe < pe1; ++pe) {
-        const PathEntry pth = f.paths[pe];
-        const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
-        const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
-        const uint64_t mlo = f.mask[pth.data * 4 + 0];
-        const uint64_t mhi = f.mask[pth.data * 4 + 1], mtop = f.mask[pth.data * 4 + 2];
-        for (int j = g; j < K; j += G) {
-            const bool on = mask_bit(mlo, mhi, mtop, j);
-            if (!on) continue;
-            const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
-            const float2 x = gld(X + (size_t)slot * P);
-            const float2 h = Hd[(size_t)j * P];
-            re = fmaf(x.x, h.x, re);
-            im = fmaf(x.y, h.y, im);
+    if (g < G) {
+        for (int pe = pe0; pe < pe1; ++pe) {
+            const PathEntry pth = f.paths[pe];
+            const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
+            const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
+            const uint64_t mlo = f.mask[pth.data * 4 + 0];
+            const uint64_t mhi = f.mask[pth.data * 4 + 1], mtop = f.mask[pth.data * 4 + 2];
+#pragma unroll 4
+            for (int j = g; j < K; j += G) {
+                const bool on = mask_bit(mlo, mhi, mtop, j);
+                const int slot = ring_slot(job.slot0, t0 + tt - j, ring);
+                const float2 x = on ? gld(X + (size_t)slot * P) : float2{0.f, 0.f};
+                const float2 h = on ? gld(Hd + (size_t)j * P) : float2{0.f, 0.f};
+                re = fmaf(x.x, h.x, re);
+                im = fmaf(x.y, h.y, im);
+            }
         }
     }
-#pragma unroll
-    for (int off = TT; off < 64; off <<= 1) {                 // sum over the G partition groups
-        re += __shfl_xor(re, off, 64);
-        im += __shfl_xor(im, off, 64);
+    part[threadIdx.x] = float2{re, im};
+    __syncthreads();
+    if (threadIdx.x < TT && t0 + tt < job.nblocks) {
+        float2 sum = part[tt];
+        for (int k = 1; k < G; ++k) {
+            const float2 v = part[tt + k * TT];
+            sum.x += v.x;
+            sum.y += v.y;
+        }
+        gst(Y + (yrow0 + tt) * P, sum);
     }
-    if (g == 0 && t0 + tt < job.nblocks) Y[(yrow0 + tt) * P] = float2{re, im};
 }
 
 // ---------------------------------------------------------------------------
