@@ -22,6 +22,8 @@ streams = [flt.open_stream(T) for _ in range(S)]
 with torch.cuda.stream(ts):
     xs = [torch.rand(T * P, 2, device="cuda") * 2 - 1 for _ in range(S)]
     ys = [torch.empty_like(x) for x in xs]
+    if os.environ.get("QB_SAME_INPUT"):          # probe: every stream reads the same (cache-resident) PCM
+        xs = [xs[0]] * S
 from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS, FE_ASYNC
 plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S, FE_DEVICE_PTRS | FE_ASYNC)
 for _ in range(3):
