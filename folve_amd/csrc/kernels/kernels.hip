@@ -843,7 +843,9 @@ struct FwdLaunch {
                           hipStream_t st) {
         if constexpr (L >= 9) {                           // 2P >= 1024: the stereo transform exists
             static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
-            if (f.cin == 2 && pairs_ok && f.twa2 && !generic) {
+            // One workgroup per block: below a chip-full of blocks the per-channel kernel's twice as many,
+            // half as long workgroups finish sooner.
+            if (f.cin == 2 && pairs_ok && f.twa2 && !generic && (long long)njobs * max_blocks >= 256) {
                 dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
                 hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
                 return hipGetLastError();
