@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
-    ap.add_argument("--blocks", type=int, default=32, help="consecutive blocks per stream per step")
+    ap.add_argument("--blocks", type=int, default=64, help="consecutive blocks per stream per step (run-ahead depth)")
     ap.add_argument("--taps", type=int, default=262144)
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")

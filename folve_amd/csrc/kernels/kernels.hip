@@ -867,8 +867,10 @@ struct InvLaunch {
             static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
             if (pairs_ok && !generic && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
                 static const char* rl = getenv("FOLVE_AMD_RUNLEN");
-                int runlen = rl ? atoi(rl) : 8;
-                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
+                // the longest walk that still gives every CU a workgroup (measured at 64 streams x 32 blocks:
+                // 512 workgroups of 4 blocks 0.107 ms, 256 of 8 0.099, 128 of 16 0.172)
+                int runlen = rl ? atoi(rl) : 32;
+                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 256) runlen >>= 1;
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
                 if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2>), grid, block, 0, st, jobs, f, Y, runlen);
                 else hipLaunchKernelGGL((inverse_walker_kernel<L, 1>), grid, block, 0, st, jobs, f, Y, runlen);
