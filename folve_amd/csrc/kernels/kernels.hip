@@ -10,9 +10,10 @@
 //     Y(n) = sum_j X(n-j) H(j) = sum_{j=0..K} Z(n-j) G(j),  G(j) = s*H(j) + H(j-1),
 // so each PCM block is read and transformed exactly once and a stream carries no
 // time-domain state — only its ring of spectra.
-//   K1 forward : block [x(n) | 0] -> Z(n) -> FDL ring row.  Stereo: ONE 2P-point complex FFT of
-//                z = L + i*R (interleaved PCM loaded as is), spectra separated by symmetry;
-//                otherwise a real FFT through a P-point complex FFT per channel
+//   K1 forward : block [x(n) | 0] -> Z(n) -> FDL ring row: a real FFT through a P-point complex FFT
+//                per channel; stereo at P = 8192 by a workgroup that walks consecutive blocks (PCM read
+//                once as quads, prefetched), stereo at smaller P as ONE 2P-point complex FFT of
+//                z = L + i*R with the spectra separated by symmetry
 //   K2 mac     : Y(n) = sum_paths sum_{j<=K} Z(n-j) * G(j), time-tiled in registers
 //   K3 inverse : Y(n) -> P-point complex IFFT in LDS -> last P samples of the
 //                window, interleaved PCM store, per-stream peak
@@ -188,7 +189,6 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
     const int tid = threadIdx.x;
     const float2* __restrict__ pcm = reinterpret_cast<const float2*>(job.in) + (size_t)b * P;   // frame t: (L, R)
     const long long left = job.nframes - (long long)b * P;                                      // valid frames
-    PH_INIT();
 
     float2 v[COLS][N1];
 #pragma unroll
@@ -208,13 +208,9 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
         if (GUARD && n2 >= N2) continue;
         stage_a_column<LOG2P + 1, false>(s, f.twa2, n2, v[c]);
     }
-    PH(0);                                                // PCM wait + stage A
     __syncthreads();
-    PH(1);
     stage_b<LOG2P + 1, false>(s, f.twb2, tid);
-    PH(2);
     __syncthreads();
-    PH(3);
     const int slot = ring_slot(job.slot0, b, job.ring);
     float2* __restrict__ rowL = job.fdl + ((size_t)0 * job.ring + slot) * P;
     float2* __restrict__ rowR = job.fdl + ((size_t)1 * job.ring + slot) * P;
@@ -234,7 +230,115 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
             gst(rowR + k, float2{0.5f * (a.y + bb.y), -0.5f * (a.x - bb.x)});
         }
     }
-    PH(4);                                                // split + stores issued
+}
+
+// ---------------------------------------------------------------------------
+// K1, stereo walker (P = 8192): the mirror image of the K3 walker.
+// grid (runs of `run` consecutive blocks, 1, streams), 512 threads.
+//
+// One workgroup owns a stream's channel pair and walks consecutive blocks.  A block's PCM is read
+// once, as 16-byte (L0, R0, L1, R1) quads that hold z[m] = x[2m] + i*x[2m+1] of BOTH channels; the
+// next block's quads are requested while the first channel transforms and fly for two transforms;
+// the split twiddles, the stage-A twiddles (registers) and the stage-B tables (spare LDS) are
+// loaded once per walk; every trip issues a fixed number of loads and stores (exact vmcnt waits).
+// ---------------------------------------------------------------------------
+template <int LOG2P>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
+                                                                             FilterDev f, int run) {
+    using G = WaveGeom<LOG2P>;
+    using S = SplitGeom<LOG2P>;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
+    static_assert(N1 == 8 && COLS == 2, "walker needs P = 8192");
+    constexpr int HR = N1 / 2;                                // rows of a column that hold PCM (the rest is the zero padding)
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    __syncthreads();
+    const StreamJob job = jobs[blockIdx.z];
+    const int b0 = blockIdx.x * run;
+    if (b0 >= job.nblocks) return;
+    const int b1 = min(b0 + run, job.nblocks);
+    const int tid = threadIdx.x;
+    const float* __restrict__ in = job.in;
+
+    float2 wsp[S::CNT];
+    split_prefetch<LOG2P>(wsp, f.tw, tid);
+    StageATw<LOG2P> atw[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) atw[c] = load_stage_a_tw<LOG2P>(f.twa, tid + c * NT);
+
+    // quads of block b: frames (2m, 2m+1), m = h*N2 + n2 over the PCM rows of this thread's columns
+    float4 q[COLS][HR], qn[COLS][HR];
+    auto request_whole = [&](float4 (&dst)[COLS][HR], const float* __restrict__ base) {
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) dst[c][h] = gld(reinterpret_cast<const float4*>(base) + (h * N2 + tid + c * NT));
+    };
+    auto request_partial = [&](float4 (&dst)[COLS][HR], int b) {   // a stream's short last block
+        const long long f0 = (long long)b * P;
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) {
+                const long long fr = f0 + 2 * (h * N2 + tid + c * NT);
+                float4 v{0.f, 0.f, 0.f, 0.f};
+                if (fr < job.nframes) { v.x = gld(in + fr * 2); v.y = gld(in + fr * 2 + 1); }
+                if (fr + 1 < job.nframes) { v.z = gld(in + fr * 2 + 2); v.w = gld(in + fr * 2 + 3); }
+                dst[c][h] = v;
+            }
+    };
+    const int bw = (int)min((long long)b1, max((long long)b0, job.nframes / P));   // blocks [b0, bw) are whole
+    PH_INIT();
+    if (b0 < bw) request_whole(q, in + (size_t)b0 * P * 2);
+    else request_partial(q, b0);
+
+    auto transform = [&](int b, int ch) {
+        int t = tid;
+        asm volatile("" : "+v"(t));                           // keeps the address arithmetic inside the loop
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            float2 z[N1];
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1)
+                z[n1] = (n1 < HR) ? (ch ? float2{q[c][n1 < HR ? n1 : 0].y, q[c][n1 < HR ? n1 : 0].w}
+                                        : float2{q[c][n1 < HR ? n1 : 0].x, q[c][n1 < HR ? n1 : 0].z})
+                                  : float2{0.0f, 0.0f};
+            stage_a_column<LOG2P, false>(s, atw[c], t + c * NT, z);
+        }
+        PH(0);                                                // PCM wait + stage A
+        __syncthreads();
+        PH(1);
+        stage_b<LOG2P, false>(s, twb_l, t);
+        PH(2);
+        __syncthreads();
+        PH(3);
+        const int slot = ring_slot(job.slot0, b, job.ring);
+        split_and_store<LOG2P>(s, wsp, t, job.fdl + ((size_t)ch * job.ring + slot) * P, 1.0f);
+        PH(4);                                                // split + stores issued
+        __syncthreads();                                      // the image is rewritten by the next stage A
+        PH(5);
+    };
+
+#pragma unroll 1
+    for (int b = b0; b < bw; ++b) {
+        // the next block flies during both transforms of this one; after the walk's last block the
+        // loads read this block again (cache-resident; the values are never used) so that every trip
+        // issues the same number of memory operations
+        request_whole(qn, in + (size_t)(b + 1 < bw ? b + 1 : b) * P * 2);
+        transform(b, 0);
+        transform(b, 1);
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) q[c][h] = qn[c][h];
+    }
+    if (bw < b1) {
+        if (bw > b0) request_partial(q, bw);
+        transform(bw, 0);
+        transform(bw, 1);
+    }
     PH_FLUSH(0);
 }
 
@@ -841,14 +945,24 @@ struct FwdLaunch {
     // pairs_ok: every stream's PCM pointer is 8-byte aligned (stereo frames loaded as float2)
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
                           hipStream_t st) {
-        if constexpr (L >= 9) {                           // 2P >= 1024: the stereo transform exists
-            static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
-            // One workgroup per block: below a chip-full of blocks the per-channel kernel's twice as many,
-            // half as long workgroups finish sooner.
-            if (f.cin == 2 && pairs_ok && f.twa2 && !generic && (long long)njobs * max_blocks >= 256) {
-                dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
-                hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
+        // Stereo fast forms, for launches that fill the chip (below that the per-channel kernel's
+        // twice as many, half as long workgroups finish sooner).
+        static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
+        if (f.cin == 2 && pairs_ok && !generic && (long long)njobs * max_blocks >= 256) {
+            if constexpr (L == 13) {
+                // P = 8192: walk consecutive blocks — the longest walk that still gives every CU a workgroup
+                static const char* rl = getenv("FOLVE_AMD_FWD_RUN");
+                int runlen = rl ? atoi(rl) : 32;
+                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 256) runlen >>= 1;
+                dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(WaveGeom<L>::NT);
+                hipLaunchKernelGGL(forward_walker_kernel<L>, grid, block, 0, st, jobs, f, runlen);
                 return hipGetLastError();
+            } else if constexpr (L >= 9) {                // 2P >= 1024: the one-transform stereo form exists
+                if (f.twa2) {
+                    dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
+                    hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
+                    return hipGetLastError();
+                }
             }
         }
         dim3 grid(max_blocks, f.cin, njobs), block(WaveGeom<L>::NT);

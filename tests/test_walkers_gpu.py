@@ -1,7 +1,8 @@
 """GPU: large batches (>= 256 blocks per launch) through the fast kernel forms — the stereo forward
-transform (forward_dual_kernel<11|12|13>: one 2P-point complex FFT per block), the mono forward path,
-and the inverse pair-walker (inverse_walker_kernel<13, 1|2>) — against the oracle and against the
-general kernels (the same streams run one at a time in small calls)."""
+walker (forward_walker_kernel<13>), the one-transform stereo form of the shorter blocks
+(forward_dual_kernel<11|12>: one 2P-point complex FFT per block), the mono forward path, and the
+inverse walker (inverse_walker_kernel<13, 1|2>) — against the oracle and against the general
+kernels (the same streams run one at a time in small calls)."""
 import numpy as np
 import pytest
 
@@ -18,7 +19,7 @@ def _rms(a):
 
 
 @pytest.mark.parametrize("channels,size,nstreams,nblocks", [
-    (2, 20000, 16, 17),     # P = 8192, K = 3: forward_dual<13> + inverse_walker<13,2>
+    (2, 20000, 16, 17),     # P = 8192, K = 3: forward_walker<13> + inverse_walker<13,2>
     (1, 20000, 16, 17),     # mono: general forward + inverse_walker<13,1>
     (2, 4000, 16, 20),      # P = 4096: forward_dual<12>, general inverse
     (1, 3000, 20, 16),      # P = 4096 mono

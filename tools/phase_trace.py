@@ -15,7 +15,7 @@ from folve_amd import capi
 from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS, FE_ASYNC
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 size, P = 262144, 8192
 ts = torch.cuda.Stream()
@@ -43,7 +43,7 @@ for _ in range(steps):
 eng.synchronize()
 assert L.fe_debug_phases(buf, 1) == 0
 names = [
-    ("forward_dual", ["PCM wait + stage A", "barrier", "stage B", "barrier", "split + stores"]),
+    ("forward_walker", ["PCM wait + stage A", "barrier", "stage B", "barrier", "split + stores", "barrier"]),
     ("inverse_walker", ["Y wait + fold", "prefetch + stage A", "barrier", "stage B", "barrier", "read + stores", "barrier"]),
 ]
 for k, (kn, ph) in enumerate(names):
