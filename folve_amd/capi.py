@@ -11,6 +11,9 @@ _LIB = None
 
 FE_HOST_PTRS, FE_DEVICE_PTRS, FE_ASYNC = 0, 1, 2
 FE_K_FORWARD, FE_K_MAC, FE_K_INVERSE, FE_K_COUNT = 0, 1, 2, 3
+FE_TUNE_FWD_RUN, FE_TUNE_INV_RUN, FE_TUNE_MAC_FORM, FE_TUNE_FFT_FORM, FE_TUNE_FAIL_NEXT = 0, 1, 2, 3, 4
+TUNE_KNOBS = {"fwd_run": FE_TUNE_FWD_RUN, "inv_run": FE_TUNE_INV_RUN, "mac_form": FE_TUNE_MAC_FORM,
+              "fft_form": FE_TUNE_FFT_FORM, "fail_next": FE_TUNE_FAIL_NEXT}
 KERNEL_NAMES = ("forward", "mac", "inverse")
 
 
@@ -58,6 +61,9 @@ ENGINE_SYMBOLS = [
     ("fe_filter_path_partitions", _i, [_vp, _i, _i]),
     ("fe_filter_get_taps", _i, [_vp, _i, _i, _vp, _i]),
     ("fe_stream_open", _i, [_vp, _i, _pvp]),
+    ("fe_host_alloc", _i, [C.c_size_t, _pvp]),
+    ("fe_host_free", None, [_vp]),
+    ("fe_stream_bind_host_buffer", _i, [_vp, _vp, C.c_size_t]),
     ("fe_stream_reset", _i, [_vp]),
     ("fe_stream_close", None, [_vp]),
     ("fe_stream_process", _i, [_vp, _vp, _i, _vp, C.POINTER(_f), C.POINTER(_f)]),
@@ -67,6 +73,8 @@ ENGINE_SYMBOLS = [
     ("fe_stream_blocks_done", _ll, [_vp]),
     ("fe_batch_process", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _i]),
     ("fe_batch_get_peaks", _i, [_pvp, _i, C.POINTER(_f), C.POINTER(_f)]),
+    ("fe_engine_set_tuning", _i, [_vp, _i, _i]),
+    ("fe_debug_xlane", _i, [_vp, _vp]),
     ("fe_engine_set_profiling", _i, [_vp, _i]),
     ("fe_engine_get_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
     ("fe_engine_reset_profile", _i, [_vp]),
@@ -133,6 +141,16 @@ class Engine:
 
     def synchronize(self):
         _chk(lib().fe_engine_synchronize(self.h), "fe_engine_synchronize")
+
+    def set_tuning(self, **knobs):
+        """Pin kernel forms on this engine (fwd_run, inv_run, mac_form, fft_form, fail_next); 0 = automatic."""
+        for name, value in knobs.items():
+            _chk(lib().fe_engine_set_tuning(self.h, TUNE_KNOBS[name], int(value)), "fe_engine_set_tuning")
+
+    def xlane_selftest(self):
+        out = np.zeros(512, np.float32)
+        _chk(lib().fe_debug_xlane(self.h, _host_ptr(out)), "fe_debug_xlane")
+        return out
 
     def set_profiling(self, on):
         _chk(lib().fe_engine_set_profiling(self.h, int(on)), "fe_engine_set_profiling")

@@ -65,18 +65,9 @@ struct fe_engine {
     std::mutex mu;
     std::map<int, float2*> tw;              // log2P -> [exp(-2 pi i k / 2P), k < 2P | stage A | stage B tables]
     std::map<int, TableOffsets> tw_off;
-    // Lanes: lane 0 is the engine's stream; lane 1 is a second HIP stream that a large
-    // batch forks half of its streams onto, so that one half's bandwidth-bound MAC runs
-    // beside the other half's latency-bound FFTs (fork/join with events per batch call).
-    struct Lane {
-        hipStream_t st = nullptr;
-        float2* Y = nullptr;
-        size_t Y_bytes = 0;
-    };
-    Lane lanes[2];
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr, stagger_ev = nullptr;
-    int max_lanes = 1;                   // FOLVE_AMD_LANES=2 turns the fork on (measured: ~1 % on MI355X)
-    long long split_min_units = 512;     // block-channels below which a batch stays on one lane
+    float2* Y = nullptr;                 // batch scratch: accumulated spectra of one launch round
+    size_t Y_bytes = 0;
+    fk::Tuning tuning;                   // launch-shape overrides (fe_engine_set_tuning)
     // rotating pinned/device buffers for job descriptors (async uploads)
     fk::StreamJob* jobs_host[kJobSlots] = {};
     fk::StreamJob* jobs_dev[kJobSlots] = {};
@@ -95,6 +86,7 @@ struct fe_engine {
     hipStream_t cp_in = nullptr, cp_out = nullptr;
     hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     // profiling
+    bool fail_next_round = false;        // test hook: the next launch round fails with FE_ERR_DEVICE
     bool profiling = false;
     hipEvent_t pev[4] = {};
     long long prof_launches[FE_K_COUNT] = {};
@@ -122,6 +114,7 @@ struct fe_filter {
     fk::PathEntry* paths_dev = nullptr;
     int* out_first_dev = nullptr;
     fk::FilterDev dev{};
+    fk::MacShape mac_shape{};
 };
 
 struct fe_stream {
@@ -133,6 +126,11 @@ struct fe_stream {
     unsigned int* peaks = nullptr; // [2]
     long long blocks_done = 0;
     int slot0 = 0;
+    // page-locked caller memory bound to this stream (fe_stream_bind_host_buffer): calls whose
+    // buffers lie inside it are read and written by the kernels directly, over the bus
+    const char* bound_host = nullptr;
+    char* bound_dev = nullptr;
+    size_t bound_bytes = 0;
 };
 
 namespace {
@@ -172,7 +170,6 @@ int get_twiddles(fe_engine* e, int log2P, fk::FftTables* out) {
 int ensure_bytes(fe_engine* e, void** ptr, size_t* have, size_t need) {
     if (*have >= need) return FE_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));   // nothing in flight may still use the old buffer
-    if (e->lanes[1].st) HIP_TRY(hipStreamSynchronize(e->lanes[1].st));
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     *have = 0;
@@ -189,15 +186,16 @@ struct Item {
     long long left;
 };
 
-// One launch round over streams that share a filter.
-// stagger: 0 none; 1 record e->stagger_ev after this round's K1; 2 wait for it before this round's K1
-// (a forked batch runs lane 1 one kernel behind lane 0, so a MAC always runs beside an FFT kernel).
-int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane_id = 0, int stagger = 0) {
-    fe_engine::Lane& lane = e->lanes[lane_id];
-    hipStream_t st = lane.st;
+// One launch round over streams that share a filter.  Host-side stream state (ring position, block
+// count) advances only after all three launches were accepted: a failed round leaves every stream
+// where it was.
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any) {
+    hipStream_t st = e->stream;
     const int P = f->P;
     std::vector<fk::StreamJob> jobs;
+    std::vector<Item*> owners;
     jobs.reserve(items.size());
+    owners.reserve(items.size());
     int yunits = 0, max_blocks = 0;
     bool in_pairs_ok = true, out_pairs_ok = true;
     for (Item& it : items) {
@@ -220,20 +218,16 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         yunits += j.nblocks * f->nout;
         max_blocks = std::max(max_blocks, j.nblocks);
         jobs.push_back(j);
-        // advance host-side state now: everything below is stream-ordered
-        s->slot0 = (s->slot0 + j.nblocks) % s->ring;
-        s->blocks_done += j.nblocks;
-        it.in += (size_t)take * f->ninp;
-        it.out += (size_t)take * f->nout;
-        it.left -= take;
+        owners.push_back(&it);
     }
     *any = !jobs.empty();
     if (jobs.empty()) return FE_OK;
 
-    int rc = ensure_bytes(e, (void**)&lane.Y, &lane.Y_bytes, (size_t)yunits * P * sizeof(float2));
+    int rc = ensure_bytes(e, (void**)&e->Y, &e->Y_bytes, (size_t)yunits * P * sizeof(float2));
     if (rc) return rc;
 
-    // upload the descriptors through a rotating pinned buffer
+    // upload the descriptors through a rotating pinned buffer; a slot is reused only after the round
+    // that read it has finished (its event is recorded behind that round's last kernel)
     const int slot = e->jobs_next;
     e->jobs_next = (e->jobs_next + 1) % kJobSlots;
     if (e->jobs_ev_pending[slot]) {
@@ -251,21 +245,30 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         e->jobs_cap[slot] = cap;
     }
     memcpy(e->jobs_host[slot], jobs.data(), bytes);
-    HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(e->jobs_ev[slot], st));
-    e->jobs_ev_pending[slot] = true;
-
+    // Small launches (the single-block path) read their descriptors straight from the page-locked
+    // buffer — no upload command in front of K1; large ones upload them once (thousands of
+    // workgroups should not each fetch a descriptor over the bus).
     const fk::StreamJob* dj = e->jobs_dev[slot];
     const int nj = (int)jobs.size();
+    if ((long long)nj * max_blocks <= 16) {
+        dj = e->jobs_host[slot];
+    } else {
+        HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+    }
+
     const bool prof = e->profiling;
+    if (e->fail_next_round) {           // test hook (fe_engine_set_tuning FE_TUNE_FAIL_NEXT): an injected device failure
+        e->fail_next_round = false;
+        return fail(FE_ERR_DEVICE, "injected device failure (test hook)");
+    }
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
-    if (stagger == 2) HIP_TRY(hipStreamWaitEvent(st, e->stagger_ev, 0));
-    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, st));
-    if (stagger == 1) HIP_TRY(hipEventRecord(e->stagger_ev, st));
+    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, e->tuning, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
-    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, lane.Y, max_blocks, st));
+    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, e->Y, max_blocks, f->mac_shape, e->tuning, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
-    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, lane.Y, out_pairs_ok, st));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, e->Y, out_pairs_ok, e->tuning, st));
+    HIP_TRY(hipEventRecord(e->jobs_ev[slot], st));
+    e->jobs_ev_pending[slot] = true;
     if (prof) {
         HIP_TRY(hipEventRecord(e->pev[3], st));
         HIP_TRY(hipEventSynchronize(e->pev[3]));
@@ -275,6 +278,17 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
             e->prof_ms[k] += ms;
             e->prof_launches[k] += 1;
         }
+    }
+    // everything is enqueued: advance the streams (all later work is stream-ordered behind it)
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        Item& it = *owners[i];
+        fe_stream* s = it.s;
+        const fk::StreamJob& j = jobs[i];
+        s->slot0 = (s->slot0 + j.nblocks) % s->ring;
+        s->blocks_done += j.nblocks;
+        it.in += (size_t)j.nframes * f->ninp;
+        it.out += (size_t)j.nframes * f->nout;
+        it.left -= j.nframes;
     }
     return FE_OK;
 }
@@ -289,35 +303,11 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         std::vector<Item> group;
         for (int k = i; k < i1; ++k)
             if (!done[(size_t)(k - i0)] && streams[k]->f == f) { group.push_back(all[(size_t)k]); done[(size_t)(k - i0)] = 1; }
-        long long units = 0;
-        for (const Item& it : group) units += (it.left + f->P - 1) / f->P * f->nout;
-        const bool split = !e->profiling && e->max_lanes > 1 && group.size() >= 2 && units >= e->split_min_units;
-        if (!split) {
-            bool any = true;
-            while (any) {
-                int rc = launch_round(e, f, group, &any, 0);
-                if (rc) return rc;
-            }
-            continue;
+        bool any = true;
+        while (any) {
+            int rc = launch_round(e, f, group, &any);
+            if (rc) return rc;
         }
-        if (!e->lanes[1].st) {
-            HIP_TRY(hipStreamCreateWithFlags(&e->lanes[1].st, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&e->stagger_ev, hipEventDisableTiming));
-        }
-        std::vector<Item> half[2];
-        for (size_t k = 0; k < group.size(); ++k) half[k >= (group.size() + 1) / 2].push_back(group[k]);
-        HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
-        HIP_TRY(hipStreamWaitEvent(e->lanes[1].st, e->fork_ev, 0));
-        bool any0 = true, any1 = true;
-        while (any0 || any1) {
-            const bool both = any0 && any1;
-            if (any0) { int rc = launch_round(e, f, half[0], &any0, 0, both ? 1 : 0); if (rc) return rc; }
-            if (any1) { int rc = launch_round(e, f, half[1], &any1, 1, both ? 2 : 0); if (rc) return rc; }
-        }
-        HIP_TRY(hipEventRecord(e->join_ev, e->lanes[1].st));
-        HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
     }
     return FE_OK;
 }
@@ -390,9 +380,41 @@ int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* c
 // peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
                    const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr) {
-    const bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
+    bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
     const bool async = device_ptrs && (flags & FE_ASYNC);
     HIP_TRY(hipSetDevice(e->device));
+
+    // Host-pointer calls whose every buffer lies in page-locked memory bound to its stream run
+    // zero-copy: the kernels read the PCM and write the result through the device's mapping of that
+    // memory.  No staging copies (two DMA commands and their latency per call): this is the
+    // single-block path of SoundProcessor::Process, where latency is everything.
+    std::vector<const float*> zc_in;
+    std::vector<float*> zc_out;
+    if (!device_ptrs && n > 0) {
+        bool all_bound = true;
+        for (int i = 0; i < n && all_bound; ++i) {
+            const fe_stream* s = streams[i];
+            if (!s || !s->bound_host || nframes[i] < 0) { all_bound = false; break; }
+            const char* lo = s->bound_host;
+            const char* hi = lo + s->bound_bytes;
+            const char* ib = reinterpret_cast<const char*>(in[i]);
+            const char* ob = reinterpret_cast<const char*>(out[i]);
+            const size_t nin = (size_t)nframes[i] * s->f->ninp * sizeof(float), nout = (size_t)nframes[i] * s->f->nout * sizeof(float);
+            if (!(ib >= lo && ib + nin <= hi && ob >= lo && ob + nout <= hi)) all_bound = false;
+        }
+        if (all_bound) {
+            zc_in.resize((size_t)n);
+            zc_out.resize((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                const fe_stream* s = streams[i];
+                zc_in[(size_t)i] = reinterpret_cast<const float*>(s->bound_dev + (reinterpret_cast<const char*>(in[i]) - s->bound_host));
+                zc_out[(size_t)i] = reinterpret_cast<float*>(s->bound_dev + (reinterpret_cast<char*>(out[i]) - s->bound_host));
+            }
+            in = zc_in.data();
+            out = zc_out.data();
+            device_ptrs = true;          // synchronous: the caller reads `out` when this returns
+        }
+    }
 
     std::vector<Item> all((size_t)n);
     std::vector<const float*> stage_out_of((size_t)n, nullptr);
@@ -426,7 +448,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         }
     }
     // worth pipelining: several streams and enough bytes that the bus time dwarfs the extra events
-    const bool pipelined = !device_ptrs && !e->profiling && e->max_lanes == 1 && n >= 4 &&
+    const bool pipelined = !device_ptrs && !e->profiling && n >= 4 &&
                            (in_floats + out_floats) * sizeof(float) >= ((size_t)16 << 20);
     if (pipelined) {
         int rc = run_pipelined(e, streams, n, in, out, nframes, all);
@@ -495,9 +517,6 @@ int fe_engine_create(int device, void* hip_stream, fe_engine** out) {
         if (r != hipSuccess) { delete e; return fail(FE_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(r)); }
         e->own_stream = true;
     }
-    e->lanes[0].st = e->stream;
-    if (const char* env = getenv("FOLVE_AMD_LANES")) e->max_lanes = atoi(env) > 1 ? 2 : 1;
-    if (const char* env = getenv("FOLVE_AMD_SPLIT_MIN")) e->split_min_units = atoll(env);
     for (int i = 0; i < kJobSlots; ++i) {
         if (hipEventCreateWithFlags(&e->jobs_ev[i], hipEventDisableTiming) != hipSuccess) {
             delete e;
@@ -517,12 +536,7 @@ static void engine_release(fe_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->tw) (void)hipFree(kv.second);
-    if (e->lanes[1].st) (void)hipStreamSynchronize(e->lanes[1].st);
-    for (auto& ln : e->lanes) if (ln.Y) (void)hipFree(ln.Y);
-    if (e->lanes[1].st) (void)hipStreamDestroy(e->lanes[1].st);
-    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
-    if (e->join_ev) (void)hipEventDestroy(e->join_ev);
-    if (e->stagger_ev) (void)hipEventDestroy(e->stagger_ev);
+    if (e->Y) (void)hipFree(e->Y);
     if (e->cp_in) { (void)hipStreamSynchronize(e->cp_in); (void)hipStreamDestroy(e->cp_in); }
     if (e->cp_out) { (void)hipStreamSynchronize(e->cp_out); (void)hipStreamDestroy(e->cp_out); }
     for (int i = 0; i < kMaxChunks; ++i) {
@@ -585,8 +599,10 @@ int fe_filter_add(fe_filter* f, int inp, int out, int step, const float* data, i
     if (inp < 0 || inp >= f->ninp || out < 0 || out >= f->nout) return fail(FE_ERR_PARAM, "bad input/output");
     if (ind0 < 0 || ind1 < ind0 || step < 1 || (!data && ind1 > ind0)) return fail(FE_ERR_PARAM, "bad range");
     const int self = inp * f->nout + out;
-    f->paths[(size_t)self].used = true;
-    PathHost& p = f->paths[(size_t)resolve(f, self)];
+    // A pair that is a link (/impulse/copy target) takes no data of its own: zita's impdata_create
+    // returns without touching a linked node, and so does this.
+    if (f->paths[(size_t)self].link >= 0) return FE_OK;
+    PathHost& p = f->paths[(size_t)self];
     p.used = true;
     const long long cap = (long long)f->K * f->P;
     if (p.taps.empty()) {
@@ -607,11 +623,14 @@ int fe_filter_link(fe_filter* f, int inp1, int out1, int inp2, int out2) {
     if (inp2 < 0 || inp2 >= f->ninp || out2 < 0 || out2 >= f->nout) return fail(FE_ERR_PARAM, "bad target pair");
     const int src = inp1 * f->nout + out1, dst = inp2 * f->nout + out2;
     if (src == dst) return fail(FE_ERR_PARAM, "cannot link a pair to itself");
-    if (resolve(f, src) == dst) return fail(FE_ERR_PARAM, "link would form a cycle");
+    // As zita's impdata_copy: nothing happens when the source pair has no node yet (no data was
+    // ever added to it, nor was it linked) or when the target already holds data of its own.
+    const PathHost& sp = f->paths[(size_t)src];
     PathHost& d = f->paths[(size_t)dst];
-    d.taps.clear();
-    d.taps.shrink_to_fit();
-    memset(d.mask, 0, sizeof(d.mask));
+    if (!sp.used) return FE_OK;
+    if (!d.taps.empty()) return FE_OK;
+    for (int at = src, guard = 0; at >= 0 && guard < 8192; at = f->paths[(size_t)at].link, ++guard)
+        if (at == dst) return fail(FE_ERR_PARAM, "link would form a cycle");   // (undefined behaviour in zita)
     d.link = src;
     d.used = true;
     return FE_OK;
@@ -645,9 +664,28 @@ int fe_filter_commit(fe_filter* f) {
     }
     out_first[(size_t)f->nout] = (int)entries.size();
 
+    // every output with exactly one input path, and how dense the populated-row bitmaps are (K2's form choice)
+    f->mac_shape.single_path = true;
+    for (int o = 0; o < f->nout; ++o)
+        if (out_first[(size_t)o + 1] - out_first[(size_t)o] > 1) f->mac_shape.single_path = false;
+    {
+        long long rows = 0, pop = 0;
+        for (int d : owners) {
+            const PathHost& p = f->paths[(size_t)d];
+            rows += K;
+            for (int w = 0; w < 4; ++w) pop += __builtin_popcount(p.mask[w]);
+        }
+        f->mac_shape.dense = rows > 0 && pop * 10 >= rows * 6;
+    }
+
     fk::FftTables tabs{};
     int rc = get_twiddles(e, f->log2P, &tabs);
     if (rc) return rc;
+    // a retry after a partial failure must not leak the earlier attempt's buffers
+    if (f->out_first_dev) { (void)hipFree(f->out_first_dev); f->out_first_dev = nullptr; }
+    if (f->paths_dev) { (void)hipFree(f->paths_dev); f->paths_dev = nullptr; }
+    if (f->H) { (void)hipFree(f->H); f->H = nullptr; }
+    if (f->mask_dev) { (void)hipFree(f->mask_dev); f->mask_dev = nullptr; }
     HIP_TRY(hipMalloc((void**)&f->out_first_dev, out_first.size() * sizeof(int)));
     HIP_TRY(hipMemcpy(f->out_first_dev, out_first.data(), out_first.size() * sizeof(int), hipMemcpyHostToDevice));
     if (!entries.empty()) {
@@ -768,6 +806,41 @@ int fe_stream_open(fe_filter* f, int max_blocks_per_call, fe_stream** out) {
     return FE_OK;
 }
 
+int fe_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(FE_ERR_PARAM, "null out");
+    *out = nullptr;
+    if (bytes == 0) return fail(FE_ERR_PARAM, "zero bytes");
+    hipError_t r = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (r != hipSuccess) {
+        *out = nullptr;
+        return fail(r == hipErrorOutOfMemory ? FE_ERR_ALLOC : FE_ERR_DEVICE, "hipHostMalloc: %s", hipGetErrorString(r));
+    }
+    return FE_OK;
+}
+
+void fe_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int fe_stream_bind_host_buffer(fe_stream* s, void* buf, size_t bytes) {
+    if (!s) return fail(FE_ERR_PARAM, "null stream");
+    fe_engine* e = s->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    s->bound_host = nullptr; s->bound_dev = nullptr; s->bound_bytes = 0;
+    if (!buf || bytes == 0) return FE_OK;            // unbind
+    void* dev = nullptr;
+    hipError_t r = hipHostGetDevicePointer(&dev, buf, 0);
+    if (r != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        return fail(FE_ERR_PARAM, "buffer is not page-locked memory the device can address (use fe_host_alloc)");
+    }
+    s->bound_host = static_cast<const char*>(buf);
+    s->bound_dev = static_cast<char*>(dev);
+    s->bound_bytes = bytes;
+    return FE_OK;
+}
+
 int fe_stream_reset(fe_stream* s) {
     if (!s) return fail(FE_ERR_PARAM, "null stream");
     fe_engine* e = s->eng;
@@ -812,6 +885,7 @@ int fe_stream_get_peaks(fe_stream* s, float* peak_signed, float* peak_abs) {
 int fe_batch_get_peaks(fe_stream* const* streams, int n, float* peak_signed, float* peak_abs) {
     if (n < 0 || (n > 0 && !streams)) return fail(FE_ERR_PARAM, "bad arguments");
     if (n == 0) return FE_OK;
+    if (!streams[0]) return fail(FE_ERR_PARAM, "stream 0 is null");
     fe_engine* e = streams[0]->eng;
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
@@ -876,9 +950,48 @@ int fe_stream_process(fe_stream* s, const float* in, int valid_frames, float* ou
     const int rc = process_locked(e, ss, 1, ii, nn, oo, FE_HOST_PTRS, (peak_signed || peak_abs) ? bits : nullptr);
     if (rc) return rc;
     float v[2];
-    memcpy(v, bits, sizeof(v));
+    memcpy(v, bits, sizeof(v));       // (zeros when no peak was asked for)
     if (peak_signed) *peak_signed = v[0];
     if (peak_abs) *peak_abs = v[1];
+    return FE_OK;
+}
+
+// ---- launch-shape overrides and device self-tests -------------------------------------------
+int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    switch (knob) {
+        case FE_TUNE_FWD_RUN:
+        case FE_TUNE_INV_RUN:
+            if (value < 0 || value > 4096) return fail(FE_ERR_PARAM, "run length out of range");
+            (knob == FE_TUNE_FWD_RUN ? e->tuning.fwd_run : e->tuning.inv_run) = value;
+            return FE_OK;
+        case FE_TUNE_MAC_FORM:
+            if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 100)
+                return fail(FE_ERR_PARAM, "MAC form must be 0, 1, 4, 8, 16 or 100");
+            e->tuning.mac_form = value;
+            return FE_OK;
+        case FE_TUNE_FFT_FORM:
+            if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "FFT form must be 0, 1 or 2");
+            e->tuning.fft_form = value;
+            return FE_OK;
+        case FE_TUNE_FAIL_NEXT:
+            e->fail_next_round = value != 0;
+            return FE_OK;
+        default:
+            return fail(FE_ERR_PARAM, "unknown tuning knob %d", knob);
+    }
+}
+
+int fe_debug_xlane(fe_engine* e, float* out512) {
+    if (!e || !out512) return fail(FE_ERR_PARAM, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    DevTmp buf;
+    HIP_TRY(hipMalloc(&buf.p, 512 * sizeof(float)));
+    HIP_TRY(fk::launch_xlane_selftest(static_cast<float*>(buf.p), e->stream));
+    HIP_TRY(hipMemcpyAsync(out512, buf.p, 512 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return FE_OK;
 }
 

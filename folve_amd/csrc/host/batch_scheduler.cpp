@@ -3,16 +3,20 @@
 #include <stdlib.h>
 
 #include <atomic>
-#include <chrono>
+#include <map>
+#include <memory>
 
 namespace folve {
 
 namespace {
 std::atomic<int> g_enabled{-1};        // -1: not decided yet (environment)
-std::atomic<int> g_window_us{150};
 std::atomic<int> g_max_batch{256};
 std::mutex g_map_mu;
-std::map<fe_engine*, BatchScheduler*> g_schedulers;
+// owned here: destroyed with the process (no threads to stop)
+std::map<fe_engine*, std::unique_ptr<BatchScheduler>>& Schedulers() {
+    static std::map<fe_engine*, std::unique_ptr<BatchScheduler>> m;
+    return m;
+}
 }  // namespace
 
 void BatchScheduler::SetEnabled(bool on) { g_enabled.store(on ? 1 : 0); }
@@ -21,82 +25,87 @@ bool BatchScheduler::Enabled() {
     int v = g_enabled.load();
     if (v < 0) {
         const char* env = getenv("FOLVE_AMD_BATCH");
-        v = (env && atoi(env) != 0) ? 1 : 0;
+        v = (env && atoi(env) == 0) ? 0 : 1;
         g_enabled.store(v);
     }
     return v == 1;
 }
 
-void BatchScheduler::Configure(int window_us, int max_batch) {
-    if (window_us >= 0) g_window_us.store(window_us);
+void BatchScheduler::Configure(int max_batch) {
     if (max_batch >= 1) g_max_batch.store(max_batch);
 }
 
 BatchScheduler* BatchScheduler::ForEngine(fe_engine* engine) {
     std::lock_guard<std::mutex> lk(g_map_mu);
-    BatchScheduler*& s = g_schedulers[engine];
-    if (!s) s = new BatchScheduler(engine);
-    return s;
+    std::unique_ptr<BatchScheduler>& s = Schedulers()[engine];
+    if (!s) s.reset(new BatchScheduler());
+    return s.get();
 }
 
-BatchScheduler::BatchScheduler(fe_engine*) : worker_([this] { Loop(); }) { worker_.detach(); }
+void BatchScheduler::ReleaseEngine(fe_engine* engine) {
+    std::lock_guard<std::mutex> lk(g_map_mu);
+    Schedulers().erase(engine);
+}
 
-int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, float* peak_signed,
-                            float* peak_abs) {
-    Request r{s, in, valid_frames, out, 0.f, 0.f, 0, false};
+int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error) {
+    Request r{s, in, valid_frames, out, 0, false, std::string()};
     std::unique_lock<std::mutex> lk(mu_);
     queue_.push_back(&r);
     stats_.requests++;
-    arrived_.notify_one();
-    finished_.wait(lk, [&r] { return r.done; });
-    if (peak_signed) *peak_signed = r.peak_signed;
-    if (peak_abs) *peak_abs = r.peak_abs;
+    while (!r.done) {
+        if (busy_) {                       // a call is in flight: park until its thread has looked at the queue
+            finished_.wait(lk);
+            continue;
+        }
+        // The GPU is idle: this thread takes everything that is parked (its own block included).
+        busy_ = true;
+        const size_t cap = static_cast<size_t>(g_max_batch.load());
+        const size_t n = queue_.size() < cap ? queue_.size() : cap;
+        std::vector<Request*> batch(queue_.begin(), queue_.begin() + static_cast<long>(n));
+        queue_.erase(queue_.begin(), queue_.begin() + static_cast<long>(n));
+        lk.unlock();
+        Run(batch);
+        lk.lock();
+        busy_ = false;
+        stats_.batches++;
+        if (static_cast<long long>(n) > stats_.largest) stats_.largest = static_cast<long long>(n);
+        for (Request* q : batch) q->done = true;
+        finished_.notify_all();            // the served threads leave; one parked thread becomes the next leader
+    }
+    if (error) *error = r.error;
     return r.rc;
 }
 
-void BatchScheduler::Loop() {
-    std::vector<Request*> batch;
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            arrived_.wait(lk, [this] { return !queue_.empty(); });
-            // collection window: other files' threads are usually a few microseconds behind
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(g_window_us.load());
-            const size_t cap = static_cast<size_t>(g_max_batch.load());
-            while (queue_.size() < cap) {
-                if (arrived_.wait_until(lk, deadline) == std::cv_status::timeout) break;
-            }
-            const size_t n = queue_.size() < cap ? queue_.size() : cap;
-            batch.assign(queue_.begin(), queue_.begin() + static_cast<long>(n));
-            queue_.erase(queue_.begin(), queue_.begin() + static_cast<long>(n));
-        }
-        const int n = static_cast<int>(batch.size());
-        std::vector<fe_stream*> ss(batch.size());
-        std::vector<const float*> ins(batch.size());
-        std::vector<float*> outs(batch.size());
-        std::vector<long long> nfr(batch.size());
-        for (int i = 0; i < n; ++i) {
-            ss[static_cast<size_t>(i)] = batch[static_cast<size_t>(i)]->s;
-            ins[static_cast<size_t>(i)] = batch[static_cast<size_t>(i)]->in;
-            outs[static_cast<size_t>(i)] = batch[static_cast<size_t>(i)]->out;
-            nfr[static_cast<size_t>(i)] = batch[static_cast<size_t>(i)]->frames;
-        }
-        const int rc = fe_batch_process(ss.data(), n, ins.data(), nfr.data(), outs.data(), FE_HOST_PTRS);
-        std::vector<float> ps(batch.size(), 0.f), pa(batch.size(), 0.f);
-        if (rc == 0) fe_batch_get_peaks(ss.data(), n, ps.data(), pa.data());
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stats_.batches++;
-            if (n > stats_.largest) stats_.largest = n;
-            for (int i = 0; i < n; ++i) {
-                Request* r = batch[static_cast<size_t>(i)];
-                r->rc = rc;
-                r->peak_signed = ps[static_cast<size_t>(i)];
-                r->peak_abs = pa[static_cast<size_t>(i)];
-                r->done = true;
-            }
-        }
-        finished_.notify_all();
+void BatchScheduler::Run(std::vector<Request*>& batch) {
+    const int n = static_cast<int>(batch.size());
+    if (n == 1) {
+        Request* r = batch[0];
+        r->rc = fe_stream_process(r->s, r->in, r->frames, r->out, NULL, NULL);
+        if (r->rc != 0) r->error = fe_last_error();
+        return;
+    }
+    std::vector<fe_stream*> ss(batch.size());
+    std::vector<const float*> ins(batch.size());
+    std::vector<float*> outs(batch.size());
+    std::vector<long long> nfr(batch.size());
+    for (int i = 0; i < n; ++i) {
+        const Request* r = batch[static_cast<size_t>(i)];
+        ss[static_cast<size_t>(i)] = r->s;
+        ins[static_cast<size_t>(i)] = r->in;
+        outs[static_cast<size_t>(i)] = r->out;
+        nfr[static_cast<size_t>(i)] = r->frames;
+    }
+    const int rc = fe_batch_process(ss.data(), n, ins.data(), nfr.data(), outs.data(), FE_HOST_PTRS);
+    if (rc == 0) {
+        for (Request* r : batch) r->rc = 0;
+        return;
+    }
+    // The batch was refused as a whole (a launch round that fails leaves its streams where they
+    // were): run the blocks one by one so that one bad stream does not fail its neighbours, and
+    // every block gets its own status and message.
+    for (Request* r : batch) {
+        r->rc = fe_stream_process(r->s, r->in, r->frames, r->out, NULL, NULL);
+        if (r->rc != 0) r->error = fe_last_error();
     }
 }
 

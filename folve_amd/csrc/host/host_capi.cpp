@@ -122,7 +122,8 @@ int fh_pool_pooled_count(fh_pool* pool, const char* config_path) {
 
 void fh_batching_set(int enabled, int window_us, int max_batch) {
     folve::BatchScheduler::SetEnabled(enabled != 0);
-    folve::BatchScheduler::Configure(window_us, max_batch);
+    (void)window_us;                       // the combiner has no collection window (kept in the signature)
+    folve::BatchScheduler::Configure(max_batch);
 }
 int fh_batching_enabled(void) { return folve::BatchScheduler::Enabled(); }
 void fh_batching_stats(long long* requests, long long* batches, long long* largest) {

@@ -81,6 +81,13 @@ void ProcessorPool::Return(SoundProcessor* processor) {
         delete processor;     // outdated: not returning it to the pool
         return;
     }
+    if (!processor->ok()) {
+        // The GPU failed under this processor: its convolver state is undefined (folve_engine.h),
+        // so it must not be handed to the next file.
+        Logf("Processor %p: discarded after an engine failure", static_cast<void*>(processor));
+        delete processor;
+        return;
+    }
     std::lock_guard<std::mutex> l(pool_mutex_);
     ProcessorList*& list = pool_[processor->config_file()];
     if (list == NULL) list = new ProcessorList();

@@ -53,17 +53,37 @@ SoundProcessor* SoundProcessor::CreateOn(fe_engine* engine, const std::string& c
     return new SoundProcessor(zita, config_file, stream);
 }
 
+// The block buffer (`buffer_`, sound-processor.cc:62-63: fragm * max(ninp, nout) floats, reused in
+// place for the output) lives in page-locked memory bound to the stream: the kernels read the PCM
+// and write the result directly in it, so a block costs three kernel launches and one wait — no
+// staging copies.  If page-locked memory cannot be had the buffer is ordinary memory and the engine
+// stages it.
+static float* AllocBlockBuffer(size_t floats, bool* pinned) {
+    void* p = NULL;
+    if (fe_host_alloc(floats * sizeof(float), &p) == 0 && p) {
+        *pinned = true;
+        return static_cast<float*>(p);
+    }
+    *pinned = false;
+    return new float[floats];
+}
+
 SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream)
     : zita_config_(config), config_file_(cfg), config_file_timestamp_(GetModificationTime(cfg)), stream_(stream),
-      buffer_(new float[static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)]),
+      buffer_floats_(static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)),
+      buffer_(AllocBlockBuffer(buffer_floats_, &buffer_pinned_)),
       input_pos_(0), output_pos_(0), max_out_value_observed_(0.0), max_abs_value_observed_(0.0), ok_(true) {
+    if (buffer_pinned_ && fe_stream_bind_host_buffer(stream_, buffer_, buffer_floats_ * sizeof(float)) != 0) {
+        Logf("Processor %p: block buffer not bound (%s): blocks will be staged", static_cast<void*>(this), fe_last_error());
+    }
     Reset();
 }
 
 SoundProcessor::~SoundProcessor() {
     fe_stream_close(stream_);
     DeviceRouter::Default()->StreamClosed(zita_config_.engine);
-    delete[] buffer_;
+    if (buffer_pinned_) fe_host_free(buffer_);
+    else delete[] buffer_;
 }
 
 int SoundProcessor::device() const { return fe_engine_device(zita_config_.engine); }
@@ -91,24 +111,36 @@ void SoundProcessor::WriteProcessed(FrameSink* out, int sample_count) {
 
 // One block through the GPU.  The reference zero-fills the unread tail, splits
 // the channels, runs Convproc::process(), re-interleaves input_pos_ frames and
-// tracks the maximum (sound-processor.cc:98-127); K1/K2/K3 do exactly that on
-// the device: frames >= input_pos_ count as zero, input_pos_ frames come back.
+// tracks the maximum (sound-processor.cc:98-127); K1/K2/K3 do the first four on
+// the device — frames >= input_pos_ count as zero, input_pos_ frames come back —
+// and the maximum is taken here over the returned frames, signed as cc:120-123 does.
 void SoundProcessor::Process() {
-    float peak_signed = 0.0f, peak_abs = 0.0f;
     if (input_pos_ > 0) {
-        // With batching on, the block joins whatever other files' threads submit within the
-        // collection window and runs as part of one launch; otherwise it is launched alone.
-        const int rc = BatchScheduler::Enabled()
-            ? BatchScheduler::ForEngine(zita_config_.engine)->Process(stream_, buffer_, input_pos_, buffer_,
-                                                                      &peak_signed, &peak_abs)
-            : fe_stream_process(stream_, buffer_, input_pos_, buffer_, &peak_signed, &peak_abs);
-        if (rc != 0) {
-            Logf("GPU convolution failed (%d): %s", rc, fe_last_error());
-            memset(buffer_, 0, sizeof(float) * static_cast<size_t>(input_pos_) * output_channels());
-            ok_ = false;
+        // The call goes through the device's combiner: alone it runs at once; while another file's
+        // block is in flight on this GPU it is parked and leaves with the next batch.
+        std::string error;
+        int rc;
+        if (BatchScheduler::Enabled()) {
+            rc = BatchScheduler::ForEngine(zita_config_.engine)->Process(stream_, buffer_, input_pos_, buffer_, &error);
         } else {
-            if (peak_signed > max_out_value_observed_) max_out_value_observed_ = peak_signed;
-            if (peak_abs > max_abs_value_observed_) max_abs_value_observed_ = peak_abs;
+            rc = fe_stream_process(stream_, buffer_, input_pos_, buffer_, NULL, NULL);
+            if (rc != 0) error = fe_last_error();
+        }
+        const size_t n = static_cast<size_t>(input_pos_) * output_channels();
+        if (rc != 0) {
+            Logf("GPU convolution failed (%d): %s", rc, error.c_str());
+            memset(buffer_, 0, sizeof(float) * n);
+            ok_ = false;                 // ProcessorPool::Return will not pool this processor
+        } else {
+            float hi = max_out_value_observed_, mag = max_abs_value_observed_;
+            for (size_t j = 0; j < n; ++j) {
+                const float v = buffer_[j];
+                hi = v > hi ? v : hi;
+                const float a = v < 0 ? -v : v;
+                mag = a > mag ? a : mag;
+            }
+            max_out_value_observed_ = hi;
+            max_abs_value_observed_ = mag;
         }
     }
     output_pos_ = 0;

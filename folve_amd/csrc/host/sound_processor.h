@@ -1,11 +1,13 @@
 // sound_processor.h — drop-in for folve's SoundProcessor on top of the GPU engine.
 //
 // Public surface and behaviour follow /root/reference/sound-processor.h:28-85 and
-// sound-processor.cc:34-145 method for method.  The only signature change is that
-// `SNDFILE*` becomes FrameSource / FrameSink (libsndfile's sf_readf_float /
-// sf_writef_float contract), so the class builds without libsndfile; when
-// <sndfile.h> is available, sndfile_adapter.h restores the exact reference
-// signatures on top of these.
+// sound-processor.cc:34-145 method for method.  The reference's two libsndfile members
+//     int  FillBuffer(SNDFILE *in);                          (sound-processor.h:35)
+//     void WriteProcessed(SNDFILE *out, int sample_count);   (sound-processor.h:55)
+// are declared here against an opaque SNDFILE and defined in sndfile_adapter.cpp, which is
+// compiled only where <sndfile.h> exists (the folve build); everything else — the block
+// machine itself — works on FrameSource / FrameSink (libsndfile's sf_readf_float /
+// sf_writef_float contract), so the library builds and is tested without libsndfile.
 #pragma once
 
 #include <time.h>
@@ -13,6 +15,9 @@
 #include <string>
 
 #include "zita_config.h"
+
+// <sndfile.h>'s own declaration of the handle type (a typedef may be repeated)
+typedef struct SNDFILE_tag SNDFILE;
 
 namespace folve {
 
@@ -44,6 +49,8 @@ public:
 
     // Fill buffer from given source.  Returns number of frames read.
     int FillBuffer(FrameSource* in);
+    // The reference's signature (sound-processor.h:35); defined in sndfile_adapter.cpp.
+    int FillBuffer(SNDFILE* in);
 
     inline int input_channels() const { return zita_config_.ninp; }
     inline int output_channels() const { return zita_config_.nout; }
@@ -57,6 +64,8 @@ public:
 
     // Write `sample_count` processed frames to `out`; processes first if necessary.
     void WriteProcessed(FrameSink* out, int sample_count);
+    // The reference's signature (sound-processor.h:55); defined in sndfile_adapter.cpp.
+    void WriteProcessed(SNDFILE* out, int sample_count);
 
     // Reset processor for re-use.
     void Reset();
@@ -85,6 +94,8 @@ private:
     const time_t config_file_timestamp_;
     fe_stream* const stream_;
 
+    const size_t buffer_floats_;
+    bool buffer_pinned_;
     float* const buffer_;
     int input_pos_;
     int output_pos_;   // written position. -1, if not processed yet.

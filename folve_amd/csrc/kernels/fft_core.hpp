@@ -83,12 +83,14 @@ FK_HD float2 cmulc(float2 a, float2 b) {
     return FK_F2(r);
 }
 // a * (wr + i*wi), wr and wi known at compile time
+// The constant pair is an SGPR operand ("s"): as a VGPR operand every distinct constant of the
+// butterflies would occupy a loop-invariant VGPR pair (about 30 VGPRs in a walker kernel).
 FK_HD float2 cmul_const(float2 a, float wr, float wi) {
     const fk_v2f t = FK_V(a) * wr;
     const fk_v2f ws = fk_v2f{wi, wi};
     fk_v2f r;                                             // r.lo = t.lo - a.hi*wi,  r.hi = t.hi + a.lo*wi
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-        : "=v"(r) : "v"(FK_V(a)), "v"(ws), "v"(t));
+        : "=v"(r) : "v"(FK_V(a)), "s"(ws), "v"(t));
     return FK_F2(r);
 }
 #else
@@ -109,6 +111,12 @@ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0
                              0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
 constexpr float kSin16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
                              1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+
+// 32nd roots of unity: cos/sin(2*pi*i/32), i = 0..7.
+constexpr float kCos32[8] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                             0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f};
+constexpr float kSin32[8] = {0.0f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f,
+                             0.70710678118654752f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f};
 
 template <int R, bool INV>
 FK_HD void dft(float2 (&v)[R]);
@@ -216,6 +224,20 @@ FK_D void gst(float2* p, float2 v) { *(FK_GLOBAL v2f*)p = v2f{v.x, v.y}; }
 FK_D void gst(float4* p, float4 v) { *(FK_GLOBAL v4f*)p = v4f{v.x, v.y, v.z, v.w}; }
 FK_D void gst_v2(float2* p, v2f v) { *(FK_GLOBAL v2f*)p = v; }
 
+// Uniform base + 32-bit per-lane byte offset: the compiler emits the SGPR-base form
+// (global_load/store v, voffset, s[base:base+1]) — one VGPR per address instead of a 64-bit pair
+// and no per-lane 64-bit address arithmetic.  The base must be wave-uniform for that.
+FK_D float2 gld_u2(const void* base, unsigned off) {
+    const v2f v = *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)base + off);
+    return float2{v.x, v.y};
+}
+FK_D float4 gld_u4(const void* base, unsigned off) {
+    const v4f v = *(const FK_GLOBAL v4f*)((const FK_GLOBAL char*)base + off);
+    return float4{v.x, v.y, v.z, v.w};
+}
+FK_D void gst_u2(void* base, unsigned off, float2 v) { *(FK_GLOBAL v2f*)((FK_GLOBAL char*)base + off) = v2f{v.x, v.y}; }
+FK_D void gst_u4(void* base, unsigned off, float4 v) { *(FK_GLOBAL v4f*)((FK_GLOBAL char*)base + off) = v4f{v.x, v.y, v.z, v.w}; }
+
 // ---- synchronisation policies ------------------------------------------------
 struct WorkgroupSync {
     static FK_D void sync() { __syncthreads(); }
@@ -291,25 +313,113 @@ FK_D void stockham_pass(float2* s, const float2* __restrict__ tw, int tid) {
     }
 }
 
+// ---- cross-lane 4 x 4 transpose ----------------------------------------------------
+// The four lanes b, b+16, b+32, b+48 of a wavefront (one lane of each 16-lane row) exchange the
+// registers r0..r3: afterwards lane 16a + b holds in r_i what lane 16i + b held in r_a.  Two
+// half exchanges of 32 lanes (v_permlane32_swap: lanes 32..63 of the first operand swap with
+// lanes 0..31 of the second) and two of 16 (v_permlane16_swap: the odd rows of the first with
+// the even rows of the second) — the register-file shuffle gfx950 adds for exactly this; no LDS
+// access, no address arithmetic.  tests/test_xlane_gpu.py pins the semantics on the device.
+FK_D void xlane_swap32(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+FK_D void xlane_swap16(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+FK_D void xlane_transpose4(float& r0, float& r1, float& r2, float& r3) {
+    xlane_swap32(r0, r2);
+    xlane_swap32(r1, r3);
+    xlane_swap16(r0, r1);
+    xlane_swap16(r2, r3);
+}
+
+// The last two passes of a wavefront's 1024-point row (radix 16 with period 16, radix 4 with
+// period 256) as ONE pass: after the radix-16 butterflies lane 16a + b holds the elements
+// 256a + b + 16r (r < 16) and the radix-4 butterflies of lane t want t + 64c + 256r' (c, r' < 4):
+// the same 16 elements per lane group {b, b+16, b+32, b+48}, transposed between lane row a and
+// register index r & 3.  So the exchange between the passes is the cross-lane transpose above
+// instead of a round trip through LDS (16 ds_write_b64 + 16 ds_read_b64 per lane saved).
+//   UPPER: write only the upper half of the row (the inverse transform's overlap-save output
+//   keeps the last P of 2P samples = the upper half of every row; the rest is never read).
+template <bool INV, bool UPPER, bool LEAN, class Sync>
+FK_D void fused_pass_16_4(float2* s, const float2* __restrict__ tw16, const float2* __restrict__ tw4, int tid) {
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = s[phys(tid + r * 64)];
+    Sync::sync();
+    {
+        // LEAN: only the power-of-two rows are read (4 ds_read_b64 instead of 15) and the other
+        // powers formed as products — 22 more packed multiplies, 22 fewer VGPRs in flight: what lets
+        // the walkers stay at 128 VGPRs (two workgroups per CU)
+        float2 w[16];
+        load_twiddles<16, 16, !LEAN>(w, tw16, tid & 15);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = INV ? cmulc(v[r], w[r]) : cmul(v[r], w[r]);
+    }
+    dft<16, INV>(v);
+    if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        xlane_transpose4(v[4 * c].x, v[4 * c + 1].x, v[4 * c + 2].x, v[4 * c + 3].x);
+        xlane_transpose4(v[4 * c].y, v[4 * c + 1].y, v[4 * c + 2].y, v[4 * c + 3].y);
+    }
+    // radix-4 twiddles W_1024^(k*r) at k = tid + 64*c: the values at k = tid (two table reads, r = 1, 2)
+    // rotated by W_16^(c*r) — compile-time constants — instead of eight table reads
+    float2 wk[4];
+    load_twiddles<4, 256, false>(wk, tw4, tid);
+    if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = tid + 64 * c;
+        float2 u[4];
+        u[0] = v[4 * c];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            const int q = (c * r) & 15;                      // W_16^q = (cos, -sin)(2*pi*q/16)
+            const float cq = (q < 8) ? kCos16[q & 7] : -kCos16[q & 7];
+            const float sq = (q < 8) ? kSin16[q & 7] : -kSin16[q & 7];
+            const float2 w = (q == 0) ? wk[r] : cmul_const(wk[r], cq, -sq);
+            u[r] = INV ? cmulc(v[4 * c + r], w) : cmul(v[4 * c + r], w);
+        }
+        dft<4, INV>(u);
+#pragma unroll
+        for (int r = UPPER ? 2 : 0; r < 4; ++r) s[phys(k + 256 * r)] = u[r];
+        if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // N-point FFT in place in one padded LDS image by NT threads: natural order in,
 // natural order out.  Ends with the data written and synchronised.
-template <int LOG2N, int NT, bool INV, class Sync>
+//   XL: a single wavefront's 1024-point row runs its last two passes fused (fused_pass_16_4).
+template <int LOG2N, int NT, bool INV, class Sync, bool XL = false, bool UPPER = false, bool LEAN = false>
 FK_D void lds_fft(float2* s, const float2* __restrict__ ptw, int tid) {
     constexpr int N = 1 << LOG2N;
     constexpr Plan pl = make_plan(LOG2N);
     static_assert(pl.n >= 2 && pl.n <= 4, "plan");
     constexpr int R0 = pl.r[0], R1 = pl.r[1], R2 = pl.r[2], R3 = pl.r[3];
-    stockham_pass<N, NT, R0, 1, INV, Sync>(s, ptw, tid);
-    Sync::sync();
-    stockham_pass<N, NT, R1, R0, INV, Sync>(s, ptw + pl.off[1], tid);
-    Sync::sync();
-    if constexpr (pl.n >= 3) {
-        stockham_pass<N, NT, R2, R0 * R1, INV, Sync>(s, ptw + pl.off[2], tid);
+    if constexpr (XL && LOG2N == 10 && NT == 64) {
+        static_assert(R0 == 16 && R1 == 16 && R2 == 4 && pl.n == 3, "1024 = 16 * 16 * 4");
+        stockham_pass<N, NT, 16, 1, INV, Sync>(s, ptw, tid);
         Sync::sync();
-    }
-    if constexpr (pl.n >= 4) {
-        stockham_pass<N, NT, R3, R0 * R1 * R2, INV, Sync>(s, ptw + pl.off[3], tid);
+        fused_pass_16_4<INV, UPPER, LEAN, Sync>(s, ptw + pl.off[1], ptw + pl.off[2], tid);
         Sync::sync();
+    } else {
+        stockham_pass<N, NT, R0, 1, INV, Sync>(s, ptw, tid);
+        Sync::sync();
+        stockham_pass<N, NT, R1, R0, INV, Sync>(s, ptw + pl.off[1], tid);
+        Sync::sync();
+        if constexpr (pl.n >= 3) {
+            stockham_pass<N, NT, R2, R0 * R1, INV, Sync>(s, ptw + pl.off[2], tid);
+            Sync::sync();
+        }
+        if constexpr (pl.n >= 4) {
+            stockham_pass<N, NT, R3, R0 * R1 * R2, INV, Sync>(s, ptw + pl.off[3], tid);
+            Sync::sync();
+        }
     }
 }
 
@@ -416,11 +526,14 @@ FK_D void stage_a(float2* s, const float2* __restrict__ twa, int tid, Src&& src)
 }
 
 // Stage B: every wavefront transforms its own row.
-template <int LOG2P, bool INV>
+//   XL: the last two passes of a 1024-point row fused through a cross-lane transpose
+//   UPPER (with XL): only the upper half of every row is written by the last pass
+//   LEAN (with XL): fewest registers (see fused_pass_16_4)
+template <int LOG2P, bool INV, bool XL = true, bool UPPER = false, bool LEAN = false>
 FK_D void stage_b(float2* s, const float2* __restrict__ twb, int tid) {
     using G = WaveGeom<LOG2P>;
     float2* row = s + (tid >> 6) * G::RS;
-    lds_fft<G::LOG2N2, 64, INV, WaveSync>(row, twb, tid & 63);
+    lds_fft<G::LOG2N2, 64, INV, WaveSync, XL, UPPER, LEAN>(row, twb, tid & 63);
 }
 
 #endif  // __HIPCC__

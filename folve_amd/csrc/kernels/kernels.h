@@ -47,16 +47,35 @@ struct FilterDev {
     const float2* twb2;
 };
 
+// Launch-shape choices of one engine (fe_engine_set_tuning; 0 = automatic everywhere).  The
+// automatic choice depends on the batch shape, so tests pin a form to reach it with small batches.
+struct Tuning {
+    int fwd_run = 0;        // K1 walker: consecutive blocks per workgroup
+    int inv_run = 0;        // K3 walker: consecutive blocks per workgroup
+    int mac_form = 0;       // K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk
+    int fft_form = 0;       // K1/K3: 1 general kernels only, 2 walkers whenever the shape allows (also small launches)
+};
+
+// What the filter's populated-row bitmaps allow K2 to assume (computed once at commit).
+struct MacShape {
+    bool single_path = false;   // every output has exactly one input path
+    bool dense = false;         // most rows of G are populated (skipping rows would save < 40 %)
+};
+
 // K1: PCM -> spectra.  grid (max blocks, cin, jobs)
-// pairs_ok: every stream's PCM pointer is 8-byte aligned (stereo frames are loaded as pairs)
+// pairs_ok: every stream's PCM pointer is 16-byte aligned (stereo frames are loaded as quads)
 hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
-                          hipStream_t st);
-// K2: Y = sum over paths and partitions of X * H.  time_tile: outputs per thread (1,2,4,8,16)
+                          const Tuning& tn, hipStream_t st);
+// K2: Y = sum over paths and partitions of X * H.  time_tile: most blocks any stream carries
 hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, float2* Y,
-                      int time_tile, hipStream_t st);
+                      int time_tile, const MacShape& shape, const Tuning& tn, hipStream_t st);
 // K3: spectra -> PCM (last P of each 2P window) + peaks.  grid (max blocks, cout, jobs)
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          bool walker_ok, hipStream_t st);
+                          bool walker_ok, const Tuning& tn, hipStream_t st);
+// Device self-test of the cross-lane exchange fft_core.hpp relies on: out[0..63] = lane ids after
+// xlane_swap32 on (lane, 100 + lane) first operand, out[64..127] second operand, out[128..255]
+// the same for xlane_swap16, out[256..511] the four registers after xlane_transpose4 of (10*i + lane/16).
+hipError_t launch_xlane_selftest(float* out512, hipStream_t st);
 struct FftTables { const float2* tw; const float2* twa; const float2* twb; const float2* twa2; const float2* twb2; };
 // K0: time-domain taps [ndata][K*P] -> Htmp [ndata][K][P] (scaled by 1/(2P)) -> G [ndata][K+1][P].
 hipError_t launch_filter_transform(const float* taps, float2* Htmp, float2* Gs, int ndata, int K, int log2P,

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "fft_core.hpp"
 
@@ -94,28 +95,45 @@ __device__ __forceinline__ void split_prefetch(float2 (&wsp)[SplitGeom<LOG2P>::C
     }
 }
 
-template <int LOG2P>
+// Branch-free: bin k pairs with bin P - k; the thread that owns k = 0 (only in the first round)
+// pairs the two self-paired bins instead — the packed (DC, Nyquist) bin 0 and bin P/2 — by
+// selecting its second operand's address and its results, not by taking another path.
+//   BATCH > 0: the scheduler may not interleave more than BATCH bin pairs (bounds the registers in flight)
+template <int LOG2P, int BATCH = 0>
 __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&wsp)[SplitGeom<LOG2P>::CNT], int tid,
                                                 float2* __restrict__ row, float scale) {
     using S = SplitGeom<LOG2P>;
     using G = WaveGeom<LOG2P>;
     constexpr int P = S::P;
+    constexpr bool GUARD = (P / 2) % S::NT != 0;
 #pragma unroll
     for (int c = 0; c < S::CNT; ++c) {
         const int k = tid + c * S::NT;
-        if (k >= P / 2) continue;
-        if (k == 0) {
-            const float2 z0 = s[G::at(0)];
-            const float2 zh = s[G::at(P / 2)];
-            gst(row, float2{(z0.x + z0.y) * scale, (z0.x - z0.y) * scale});   // (DC, Nyquist)
-            gst(row + P / 2, float2{zh.x * scale, -zh.y * scale});
+        if (GUARD && k >= P / 2) continue;
+        const bool self = (c == 0) && (k == 0);
+        const int k2 = self ? P / 2 : P - k;
+        const float2 a = s[G::at(k)], b = s[G::at(k2)];
+        const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
+        const float2 o = float2{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
+        const float2 t = cmul(o, wsp[c]);
+        float2 r1 = float2{(e.x + t.x) * scale, (e.y + t.y) * scale};
+        float2 r2 = float2{(e.x - t.x) * scale, -(e.y - t.y) * scale};
+        if (c == 0) {
+            r1 = self ? float2{(a.x + a.y) * scale, (a.x - a.y) * scale} : r1;   // (DC, Nyquist)
+            r2 = self ? float2{b.x * scale, -b.y * scale} : r2;                   // bin P/2
+        }
+        // row is wave-uniform: the round's share of the address goes into the scalar base, and two
+        // per-lane offsets (tid, NT - 1 - tid) serve all rounds
+        if (c == 0) {
+            gst_u2(row, (unsigned)k * 8u, r1);
+            gst_u2(row, (unsigned)k2 * 8u, r2);
         } else {
-            const float2 a = s[G::at(k)], b = s[G::at(P - k)];
-            const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
-            const float2 o = float2{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
-            const float2 t = cmul(o, wsp[c]);
-            gst(row + k, float2{(e.x + t.x) * scale, (e.y + t.y) * scale});
-            gst(row + (P - k), float2{(e.x - t.x) * scale, -(e.y - t.y) * scale});
+            gst_u2(row + c * S::NT, (unsigned)tid * 8u, r1);
+            gst_u2(row + (P - c * S::NT - (S::NT - 1)), (unsigned)(S::NT - 1 - tid) * 8u, r2);
+        }
+        if constexpr (BATCH > 0) {
+            // a compiler-level memory barrier: the next batch's LDS reads stay behind this batch's stores
+            if ((c + 1) % BATCH == 0 && c + 1 < S::CNT) asm volatile("" ::: "memory");
         }
     }
 }
@@ -234,22 +252,26 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
 
 // ---------------------------------------------------------------------------
 // K1, stereo walker (P = 8192): the mirror image of the K3 walker.
-// grid (runs of `run` consecutive blocks, 1, streams), 512 threads.
+// grid (runs of `run` consecutive blocks, 1, streams), 512 threads, TWO workgroups per CU.
 //
 // One workgroup owns a stream's channel pair and walks consecutive blocks.  A block's PCM is read
 // once, as 16-byte (L0, R0, L1, R1) quads that hold z[m] = x[2m] + i*x[2m+1] of BOTH channels; the
-// next block's quads are requested while the first channel transforms and fly for two transforms;
-// the split twiddles, the stage-A twiddles (registers) and the stage-B tables (spare LDS) are
-// loaded once per walk; every trip issues a fixed number of loads and stores (exact vmcnt waits).
+// next block's quads are requested as soon as the second channel's stage A has consumed the
+// current ones and fly during its stage B and split.  Everything loop-invariant costs 8 VGPRs: the
+// stage-A twiddles of the thread's second column and the split twiddles of its eight bins are the
+// table values of the FIRST column / bin rotated by compile-time constants (columns 512 apart,
+// bins 512 apart), so one table read per kind serves the whole walk.  That keeps the kernel at
+// <= 128 VGPRs: two workgroups (2 x 78 KB of LDS) share a CU, and one's memory phases overlap the
+// other's LDS phases.  Every trip issues a fixed number of loads and stores (exact vmcnt waits).
+//   XL: stage B's last two passes exchange through the cross-lane transpose (fft_core.hpp)
 // ---------------------------------------------------------------------------
-template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
-                                                                             FilterDev f, int run) {
+template <int LOG2P, bool XL>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
+                                                                                FilterDev f, int run) {
     using G = WaveGeom<LOG2P>;
-    using S = SplitGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
-    static_assert(N1 == 8 && COLS == 2, "walker needs P = 8192");
+    static_assert(N1 == 8 && COLS == 2 && NT == 512, "walker needs P = 8192");
     constexpr int HR = N1 / 2;                                // rows of a column that hold PCM (the rest is the zero padding)
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
@@ -262,21 +284,20 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
     const int tid = threadIdx.x;
     const float* __restrict__ in = job.in;
 
-    float2 wsp[S::CNT];
-    split_prefetch<LOG2P>(wsp, f.tw, tid);
-    StageATw<LOG2P> atw[COLS];
-#pragma unroll
-    for (int c = 0; c < COLS; ++c) atw[c] = load_stage_a_tw<LOG2P>(f.twa, tid + c * NT);
+    // stage A rows k1 = 1, 2, 4 at column tid; split twiddle e^(-i*pi*k/P) at k = tid
+    const float2 a1_ = f.twa[0 * N2 + tid], a2_ = f.twa[1 * N2 + tid], a4_ = f.twa[2 * N2 + tid];
+    const float2 w0_ = f.tw[tid];
 
-    // quads of block b: frames (2m, 2m+1), m = h*N2 + n2 over the PCM rows of this thread's columns
-    float4 q[COLS][HR], qn[COLS][HR];
-    auto request_whole = [&](float4 (&dst)[COLS][HR], const float* __restrict__ base) {
+    // quads of block b: frames (2m, 2m+1), m = h*N2 + n2 over the PCM rows of this thread's columns.
+    // Registers across a stage B are what decides 128 VGPRs: the quads of a block are requested in
+    // two halves (one column each), the first before the second channel's stage B, the second after
+    // it, and the second channel's samples wait as pairs (16 VGPRs), not as quads.
+    float4 q[COLS][HR];
+    auto request_whole = [&](int c, const float* __restrict__ base) {
 #pragma unroll
-        for (int c = 0; c < COLS; ++c)
-#pragma unroll
-            for (int h = 0; h < HR; ++h) dst[c][h] = gld(reinterpret_cast<const float4*>(base) + (h * N2 + tid + c * NT));
+        for (int h = 0; h < HR; ++h) q[c][h] = gld_u4(base + (size_t)(h * N2 + c * NT) * 4, (unsigned)tid * 16u);
     };
-    auto request_partial = [&](float4 (&dst)[COLS][HR], int b) {   // a stream's short last block
+    auto request_partial = [&](int b) {                       // a stream's short last block
         const long long f0 = (long long)b * P;
 #pragma unroll
         for (int c = 0; c < COLS; ++c)
@@ -286,58 +307,96 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_walker_kernel(con
                 float4 v{0.f, 0.f, 0.f, 0.f};
                 if (fr < job.nframes) { v.x = gld(in + fr * 2); v.y = gld(in + fr * 2 + 1); }
                 if (fr + 1 < job.nframes) { v.z = gld(in + fr * 2 + 2); v.w = gld(in + fr * 2 + 3); }
-                dst[c][h] = v;
+                q[c][h] = v;
             }
     };
     const int bw = (int)min((long long)b1, max((long long)b0, job.nframes / P));   // blocks [b0, bw) are whole
     PH_INIT();
-    if (b0 < bw) request_whole(q, in + (size_t)b0 * P * 2);
-    else request_partial(q, b0);
+    if (b0 < bw) { request_whole(0, in + (size_t)b0 * P * 2); request_whole(1, in + (size_t)b0 * P * 2); }
+    else request_partial(b0);
 
-    auto transform = [&](int b, int ch) {
-        int t = tid;
-        asm volatile("" : "+v"(t));                           // keeps the address arithmetic inside the loop
+    // Opaque copies, taken inside the loop: everything derived from the four table values (the
+    // rotated twiddles, the products W^3, W^5 ..) is then recomputed per transform — a few dozen VALU
+    // — instead of hoisted out of the loop into ~50 loop-invariant registers.
+    auto opaque = [](float2 v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); return v; };
+    auto stage_a_ch = [&](const float2 (&x)[COLS][HR], int t) {
+        const float2 a1 = opaque(a1_), a2 = opaque(a2_), a4 = opaque(a4_);
 #pragma unroll
         for (int c = 0; c < COLS; ++c) {
             float2 z[N1];
 #pragma unroll
-            for (int n1 = 0; n1 < N1; ++n1)
-                z[n1] = (n1 < HR) ? (ch ? float2{q[c][n1 < HR ? n1 : 0].y, q[c][n1 < HR ? n1 : 0].w}
-                                        : float2{q[c][n1 < HR ? n1 : 0].x, q[c][n1 < HR ? n1 : 0].z})
-                                  : float2{0.0f, 0.0f};
-            stage_a_column<LOG2P, false>(s, atw[c], t + c * NT, z);
+            for (int n1 = 0; n1 < N1; ++n1) z[n1] = (n1 < HR) ? x[c][n1 < HR ? n1 : 0] : float2{0.0f, 0.0f};
+            StageATw<LOG2P> tw;
+            if (c == 0) {
+                tw.w[0] = a1; tw.w[1] = a2; tw.w[2] = a4;
+            } else {                                          // column tid + 512: W^(512*k1) = e^(-i*pi*k1/8)
+                tw.w[0] = cmul_const(a1, kCos16[1], -kSin16[1]);
+                tw.w[1] = cmul_const(a2, kCos16[2], -kSin16[2]);
+                tw.w[2] = float2{a4.y, -a4.x};
+            }
+            tw.w[3] = float2{1.f, 0.f};
+            stage_a_column<LOG2P, false>(s, tw, t + c * NT, z);
         }
+    };
+    auto split = [&](int b, int ch, int t) {                  // real-FFT split, FDL row store
+        float2 wsp[SplitGeom<LOG2P>::CNT];                    // bins t + 512*c: e^(-i*pi*512*c/P) = e^(-i*pi*c/16)
+        const float2 w0 = opaque(w0_);
+#pragma unroll
+        for (int c = 0; c < SplitGeom<LOG2P>::CNT; ++c) wsp[c] = c ? cmul_const(w0, kCos32[c], -kSin32[c]) : w0;
+        const int slot = ring_slot(job.slot0, b, job.ring);
+        split_and_store<LOG2P>(s, wsp, t, job.fdl + ((size_t)ch * job.ring + slot) * P, 1.0f);
+    };
+    // One block, both channels.  NEXT: the block `next` is requested on the way.
+    auto do_block = [&]<bool NEXT>(std::bool_constant<NEXT>, int b, const float* __restrict__ next, int t) {
+        float2 x[COLS][HR], x1[COLS][HR];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) {
+                x[c][h] = float2{q[c][h].x, q[c][h].z};
+                x1[c][h] = float2{q[c][h].y, q[c][h].w};
+            }
+        stage_a_ch(x, t);
         PH(0);                                                // PCM wait + stage A
         __syncthreads();
         PH(1);
-        stage_b<LOG2P, false>(s, twb_l, t);
+        stage_b<LOG2P, false, XL>(s, twb_l, t);
         PH(2);
         __syncthreads();
         PH(3);
-        const int slot = ring_slot(job.slot0, b, job.ring);
-        split_and_store<LOG2P>(s, wsp, t, job.fdl + ((size_t)ch * job.ring + slot) * P, 1.0f);
-        PH(4);                                                // split + stores issued
+        split(b, 0, t);
+        PH(4);
         __syncthreads();                                      // the image is rewritten by the next stage A
+        PH(5);
+        stage_a_ch(x1, t);
+        __builtin_amdgcn_sched_barrier(0);                    // the loads are not hoisted into stage A (registers)
+        if constexpr (NEXT) request_whole(0, next);                     // flies during this channel's stage B and split
+        PH(0);
+        __syncthreads();
+        PH(1);
+        stage_b<LOG2P, false, XL>(s, twb_l, t);
+        PH(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT) request_whole(1, next);                     // flies during the split
+        __syncthreads();
+        PH(3);
+        split(b, 1, t);
+        PH(4);
+        __syncthreads();
         PH(5);
     };
 
 #pragma unroll 1
     for (int b = b0; b < bw; ++b) {
-        // the next block flies during both transforms of this one; after the walk's last block the
-        // loads read this block again (cache-resident; the values are never used) so that every trip
-        // issues the same number of memory operations
-        request_whole(qn, in + (size_t)(b + 1 < bw ? b + 1 : b) * P * 2);
-        transform(b, 0);
-        transform(b, 1);
-#pragma unroll
-        for (int c = 0; c < COLS; ++c)
-#pragma unroll
-            for (int h = 0; h < HR; ++h) q[c][h] = qn[c][h];
+        int t = tid;
+        asm volatile("" : "+v"(t));                           // keeps the address arithmetic inside the loop
+        // after the walk's last block the loads read this block again (cache-resident; the values are
+        // never used) so that every trip issues the same number of memory operations
+        do_block(std::true_type{}, b, in + (size_t)(b + 1 < bw ? b + 1 : b) * P * 2, t);
     }
     if (bw < b1) {
-        if (bw > b0) request_partial(q, bw);
-        transform(bw, 0);
-        transform(bw, 1);
+        if (bw > b0) request_partial(bw);
+        do_block(std::false_type{}, bw, nullptr, tid);
     }
     PH_FLUSH(0);
 }
@@ -521,28 +580,28 @@ constexpr float kMidSin8[8] = {0.19509032201612825f, 0.55557023301960218f, 0.831
 
 // ---------------------------------------------------------------------------
 // K3, fast form ("pair-walker"): mono / stereo output, P = 8192.
-// grid (runs of `run` consecutive blocks, 1, streams)
+// grid (runs of `run` consecutive blocks, 1, streams), 512 threads, TWO workgroups per CU.
 //
 // One workgroup owns the stream's output channel pair and walks `run` consecutive
-// blocks.  The fold twiddles e^(-i*pi*k/P) depend only on the thread's columns, so
-// they are loaded once and stay in registers for the whole walk; the Y row of the
-// next FFT is requested as soon as the fold has consumed the current one; the first
-// channel's samples wait in registers for the second's, and the block leaves as
-// whole (L0, R0, L1, R1) quads — 16 bytes per lane, full lines — instead of two
-// workgroups interleaving 4-byte stores.
+// blocks.  The fold twiddles e^(-i*pi*k/P) of a thread's eight bins are 1024 bins apart:
+// one table value rotated by the 16th roots of unity (constants), so they cost 2 VGPRs
+// for the whole walk; the Y row of the next FFT is requested as soon as the fold has
+// consumed the current one; the first channel's samples wait in registers for the
+// second's, and the block leaves as whole (L0, R0, L1, R1) quads — 16 bytes per lane,
+// full lines — instead of two workgroups interleaving 4-byte stores.  Held to 128 VGPRs:
+// two workgroups share a CU and cover each other's barriers and memory waits.
 // ---------------------------------------------------------------------------
-template <int LOG2P, int COUT>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(const StreamJob* __restrict__ jobs,
-                                                                             FilterDev f,
-                                                                             const float2* __restrict__ Y, int run) {
+template <int LOG2P, int COUT, bool XL>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(const StreamJob* __restrict__ jobs,
+                                                                                FilterDev f,
+                                                                                const float2* __restrict__ Y, int run) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
     static_assert(N1 == 8 && NT == N2 / 2, "walker needs P = 8192 (one column pair per thread)");
     constexpr int OUTS = (P / 2) / NT;                        // output complex samples per thread (8)
-    // LDS: the FFT image, then the stage-B pass tables.  One workgroup fits per CU anyway
-    // (registers), so the spare LDS is free; with the tables there the loop waits on vmcnt only for
-    // the prefetched Y row — vmcnt returns in order, so a table load inside the loop would also wait
+    // LDS: the FFT image, then the stage-B pass tables: the loop waits on vmcnt only for the
+    // prefetched Y row — vmcnt returns in order, so a table load inside the loop would also wait
     // for the prefetch and the previous block's stores.
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
@@ -557,19 +616,27 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
     // column pair of this thread: (p, N2 - p); thread 0 owns the self-paired columns 0 and N2/2
     const int ca = tid, cb = (tid == 0) ? N2 / 2 : N2 - tid;
 
-    float2 wa[N1];                                            // e^(-i*pi*k/P), k = n1*N2 + ca
-#pragma unroll
-    for (int n1 = 0; n1 < N1; ++n1) wa[n1] = tw[n1 * N2 + ca];
-    const StageATw<LOG2P> atw_a = load_stage_a_tw<LOG2P>(f.twa, ca);   // loop-invariant: kept in registers
-    const StageATw<LOG2P> atw_b = load_stage_a_tw<LOG2P>(f.twa, cb);
+    const float2 wb_ = tw[ca];                                // e^(-i*pi*k/P) at k = ca; k = n1*N2 + ca is a rotation by e^(-i*pi*n1/8)
+    StageATw<LOG2P> atw_a_ = load_stage_a_tw<LOG2P>(f.twa, ca);  // loop-invariant: kept in registers (rows k1 = 1, 2, 4)
+    StageATw<LOG2P> atw_b_ = load_stage_a_tw<LOG2P>(f.twa, cb);
+    atw_a_.w[3] = atw_b_.w[3] = float2{1.f, 0.f};
 
     auto row_of = [&](int b, int o) { return Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P; };
+    // The next Y row is requested in two halves (one column of the pair each): the first as soon as
+    // the fold has consumed the current row — it flies during stages A and B —, the second after
+    // stage B: 16 instead of 32 VGPRs in flight across the transform, which is what lets two
+    // workgroups share a CU.
     float2 ya[N1], yb[N1];
-    auto request = [&](const float2* __restrict__ y) {
+    auto request_a = [&](const float2* __restrict__ y) {
 #pragma unroll
-        for (int n1 = 0; n1 < N1; ++n1) { ya[n1] = y[n1 * N2 + ca]; yb[n1] = y[n1 * N2 + cb]; }
+        for (int n1 = 0; n1 < N1; ++n1) ya[n1] = gld_u2(y + n1 * N2, (unsigned)ca * 8u);
     };
-    request(row_of(b0, 0));
+    auto request_b = [&](const float2* __restrict__ y) {
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) yb[n1] = gld_u2(y + n1 * N2, (unsigned)cb * 8u);
+    };
+    request_a(row_of(b0, 0));
+    request_b(row_of(b0, 0));
     float* __restrict__ out = job.out;
     float pk_s = 0.0f, pk_a = 0.0f;
     PH_INIT();
@@ -589,13 +656,22 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
             asm volatile("" : "+v"(t));
             // ---- Hermitian fold in registers (see inverse_kernel) ----
             float2 za[N1], zb[N1];
+            float2 wb = wb_;                                  // opaque: the rotated twiddles are recomputed, not hoisted
+            asm volatile("" : "+v"(wb.x), "+v"(wb.y));
+            StageATw<LOG2P> atw_a = atw_a_, atw_b = atw_b_;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                asm volatile("" : "+v"(atw_a.w[r].x), "+v"(atw_a.w[r].y));
+                asm volatile("" : "+v"(atw_b.w[r].x), "+v"(atw_b.w[r].y));
+            }
             if (t != 0) {
 #pragma unroll
                 for (int n1 = 0; n1 < N1; ++n1) {
                     const float2 a = ya[n1], bb = yb[N1 - 1 - n1];
                     const float2 e = cadd_conj(a, bb);
                     const float2 dd = csub_conj(a, bb);
-                    const float2 oo = cmulc(dd, wa[n1]);
+                    const float2 wa = n1 ? cmul_const(wb, kCos16[n1], -kSin16[n1]) : wb;
+                    const float2 oo = cmulc(dd, wa);
                     za[n1] = cadd_i(e, oo);
                     zb[N1 - 1 - n1] = conj_csub_i(e, oo);
                 }
@@ -609,7 +685,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
                         const float2 a = ya[n1], bb = ya[N1 - n1];
                         const float2 e = cadd_conj(a, bb);
                         const float2 dd = csub_conj(a, bb);
-                        const float2 oo = cmulc(dd, wa[n1]);
+                        const float2 oo = cmul_const(dd, kCos16[n1], kSin16[n1]);   // thread 0: k = n1*N2, conj(e^(-i*pi*n1/8))
                         za[n1] = cadd_i(e, oo);
                     }
                     const float2 a = yb[n1], bb = yb[N1 - 1 - n1];
@@ -623,14 +699,15 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
             // The next row flies during this FFT.  The loads are unconditional so that the trip's
             // memory-operation count is fixed; after the walk's last row they read the (cache-resident,
             // 2P-entry) twiddle table instead of a row, and the values are never used.
-            if (o + 1 < COUT) request(row_of(b, o + 1));
-            else request(b + 1 < b1 ? row_of(b + 1, 0) : tw);
+            const float2* __restrict__ nrow = (o + 1 < COUT) ? row_of(b, o + 1) : (b + 1 < b1 ? row_of(b + 1, 0) : tw);
+            request_a(nrow);
             stage_a_column<LOG2P, true>(s, atw_a, t, za);
             stage_a_column<LOG2P, true>(s, atw_b, (t == 0) ? N2 / 2 : N2 - t, zb);
             PH(1);
             __syncthreads();
             PH(2);
-            stage_b<LOG2P, true>(s, twb_l, t);
+            stage_b<LOG2P, true, XL, XL>(s, twb_l, t);              // XL: only the upper half of every row (the kept samples) is written
+            request_b(nrow);
             PH(3);
             __syncthreads();
             PH(4);
@@ -648,7 +725,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
                     if constexpr (COUT == 2) {
                         const float2 l = zl[c];
                         if constexpr (WHOLE) {
-                            gst(reinterpret_cast<float4*>(out + fr * 2), float4{l.x, z.x, l.y, z.y});
+                            gst_u4(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
                             pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
                             pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
                         } else {
@@ -665,7 +742,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_walker_kernel(con
                         }
                     } else {
                         if constexpr (WHOLE) {
-                            gst(reinterpret_cast<float2*>(out + fr), z);
+                            gst_u2(out + (fb + 2 * c * NT), (unsigned)t * 8u, z);
                             pk_s = fmaxf(pk_s, fmaxf(z.x, z.y));
                             pk_a = fmaxf(pk_a, fmaxf(fabsf(z.x), fabsf(z.y)));
                         } else {
@@ -925,6 +1002,133 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
     mac_packed_bin0<TT>(job, f, Y, t0, pe0, pe1, yrow0);
 }
 
+// ---------------------------------------------------------------------------
+// K2, whole-call walk: one thread owns one bin of one (stream, output) for the WHOLE call.
+// Per bin the MAC is a length-K FIR along time; the thread keeps the filter's K rows of that bin
+// (KR registers pairs) and a window of the last K input spectra of that bin in registers and walks
+// the call's blocks in order: per output block ONE new X element is loaded, ONE Y element stored,
+// K complex MACs issued.  Every X row is read from HBM exactly once per call (plus the K - 1 rows
+// of history at the start) and every Y row written once: HBM bytes per output bin
+// 8*(K - 1 + T)/T + 8 against 8*(K + 16)/16 + 8 of the 16-output sliding window.
+//
+// The window is a ring of W = KR + D register pairs: block t lives in slot t mod W, and the D
+// slots beyond the K rows still needed receive the loads of blocks t+1 .. t+D while they are in
+// flight — the window IS the prefetch buffer.  The t loop is unrolled by W, so every slot index
+// (u - j) mod W is static: no register moves, no indexing.
+//   one path per output (the launcher checks), K <= KR, bin 0 (packed DC / Nyquist) by the tail.
+// ---------------------------------------------------------------------------
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int KR, int D>
+__global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : 3) void mac_walk_kernel(
+    const StreamJob* __restrict__ jobs, FilterDev f, float2* __restrict__ Y) {
+    constexpr int W = KR + D;
+    const StreamJob job = jobs[blockIdx.z];
+    const int o = blockIdx.y;
+    const int nb = job.nblocks;
+    const int P = f.P, K = f.K, ring = job.ring;
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
+    const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * nb;
+    if (pe1 > pe0) {
+        const PathEntry pth = f.paths[pe0];
+        const v2f* __restrict__ Hd = reinterpret_cast<const v2f*>(f.H + (size_t)pth.data * K * P) + bin;
+        const v2f* __restrict__ X = reinterpret_cast<const v2f*>(job.fdl + (size_t)pth.in_ch * ring * P) + bin;
+        v2f g[KR], w[W];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) g[j] = (j < K) ? vload(Hd + (size_t)j * P) : v2f{0.f, 0.f};
+        // history: block -j in slot W - j (j = 1 .. K-1); the call's first D blocks in slots 0 .. D-1
+#pragma unroll
+        for (int j = 1; j < KR; ++j)
+            w[W - j] = (j < K) ? vload(X + (size_t)ring_slot(job.slot0, -j, ring) * P) : v2f{0.f, 0.f};
+        int xs = job.slot0;                                 // ring slot of the next block to request
+        w[D] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            w[d] = v2f{0.f, 0.f};
+            if (d < nb) {
+                w[d] = vload(X + (size_t)xs * P);
+                xs = (xs + 1 == ring) ? 0 : xs + 1;
+            }
+        }
+        float2* __restrict__ yp = Y + yrow0 * P + bin;
+        for (int t0 = 0; t0 < nb; t0 += W) {
+            // unrolled by W through a fold expression (every window index a compile-time constant; the
+            // loop unroller gives up on a body of this size)
+            static_for<W>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int t = t0 + u;
+                if (t < nb) {
+                    // block t + D rides in while blocks t .. t+D-1 are used: its slot held block t - KR, no longer needed
+                    if (t + D < nb) {
+                        w[(u + D) % W] = vload(X + (size_t)xs * P);
+                        xs = (xs + 1 == ring) ? 0 : xs + 1;
+                    }
+                    v2f acc0{0.f, 0.f}, acc1{0.f, 0.f};
+                    static_for<KR>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j & 1) cmacv(acc1, w[(u - j + 2 * W) % W], g[j]);
+                        else cmacv(acc0, w[(u - j + 2 * W) % W], g[j]);
+                    });
+                    if (bin != 0) gst_v2(yp, acc0 + acc1);
+                    yp += P;
+                }
+            });
+        }
+    } else {
+        // an output without an input path: silence
+        for (int t = 0; t < nb; ++t) gst_v2(Y + (yrow0 + t) * P + bin, v2f{0.f, 0.f});
+    }
+    // packed bin 0 = (DC, Nyquist): two real FIRs, by the workgroup that owns bin 0, 64 outputs at a
+    // time: thread -> (output t & 63, partition group t >> 6), the groups summed through LDS
+    if (blockIdx.x != 0) return;
+    __shared__ float2 part[256];
+    const int tt = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
+    for (int t0 = 0; t0 < nb; t0 += 64) {
+        float re = 0.f, im = 0.f;
+        if (pe1 > pe0 && t0 + tt < nb) {
+            const PathEntry pth = f.paths[pe0];
+            const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
+            const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
+            for (int j = grp; j < K; j += ngrp) {
+                const float2 x = gld(X + (size_t)ring_slot(job.slot0, t0 + tt - j, ring) * P);
+                const float2 h = gld(Hd + (size_t)j * P);
+                re = fmaf(x.x, h.x, re);
+                im = fmaf(x.y, h.y, im);
+            }
+        }
+        part[threadIdx.x] = float2{re, im};
+        __syncthreads();
+        if (threadIdx.x < 64 && t0 + tt < nb) {
+            float2 sum = part[tt];
+            for (int k = 1; k < ngrp; ++k) { sum.x += part[tt + 64 * k].x; sum.y += part[tt + 64 * k].y; }
+            gst(Y + (yrow0 + t0 + tt) * P, sum);
+        }
+        __syncthreads();
+    }
+}
+
+// the cross-lane exchanges of fft_core.hpp on lane ids (tests/test_xlane_gpu.py)
+__global__ __launch_bounds__(64) void xlane_selftest_kernel(float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    float a = (float)lane, b = 100.f + (float)lane;
+    xlane_swap32(a, b);
+    out[lane] = a; out[64 + lane] = b;
+    a = (float)lane; b = 100.f + (float)lane;
+    xlane_swap16(a, b);
+    out[128 + lane] = a; out[192 + lane] = b;
+    float r0 = (float)(lane / 16), r1 = 10.f + (float)(lane / 16), r2 = 20.f + (float)(lane / 16), r3 = 30.f + (float)(lane / 16);
+    xlane_transpose4(r0, r1, r2, r3);
+    out[256 + lane] = r0; out[320 + lane] = r1; out[384 + lane] = r2; out[448 + lane] = r3;
+}
+
 template <template <int> class Fn, class... A>
 hipError_t dispatch_log2p(int log2P, A&&... a) {
     switch (log2P) {
@@ -940,22 +1144,28 @@ hipError_t dispatch_log2p(int log2P, A&&... a) {
     }
 }
 
+// Walker run length: the longest walk (<= 32 blocks) that still gives every CU two workgroups.
+static int auto_run(int njobs, int max_blocks) {
+    int runlen = 32;
+    while (runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 512) runlen >>= 1;
+    return runlen;
+}
+
 template <int L>
 struct FwdLaunch {
-    // pairs_ok: every stream's PCM pointer is 8-byte aligned (stereo frames loaded as float2)
+    // pairs_ok: every stream's PCM pointer is 16-byte aligned (stereo frames loaded as quads / pairs)
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
-                          hipStream_t st) {
+                          const Tuning& tn, hipStream_t st) {
         // Stereo fast forms, for launches that fill the chip (below that the per-channel kernel's
         // twice as many, half as long workgroups finish sooner).
-        static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
-        if (f.cin == 2 && pairs_ok && !generic && (long long)njobs * max_blocks >= 256) {
+        const bool fast = tn.fft_form != 1 && f.cin == 2 && pairs_ok &&
+                          (tn.fft_form == 2 || (long long)njobs * max_blocks >= 256);
+        if (fast) {
             if constexpr (L == 13) {
-                // P = 8192: walk consecutive blocks — the longest walk that still gives every CU a workgroup
-                static const char* rl = getenv("FOLVE_AMD_FWD_RUN");
-                int runlen = rl ? atoi(rl) : 32;
-                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 256) runlen >>= 1;
+                // P = 8192: walk consecutive blocks
+                const int runlen = tn.fwd_run > 0 ? tn.fwd_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(WaveGeom<L>::NT);
-                hipLaunchKernelGGL(forward_walker_kernel<L>, grid, block, 0, st, jobs, f, runlen);
+                hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jobs, f, runlen);
                 return hipGetLastError();
             } else if constexpr (L >= 9) {                // 2P >= 1024: the one-transform stereo form exists
                 if (f.twa2) {
@@ -974,20 +1184,17 @@ template <int L>
 struct InvLaunch {
     // pairs_ok: every stream's output pointer is 16-byte aligned
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          bool pairs_ok, hipStream_t st) {
+                          bool pairs_ok, const Tuning& tn, hipStream_t st) {
         constexpr int NT = WaveGeom<L>::NT;
         if constexpr (L == 13) {      // P = 8192 (every filter longer than 4096 taps): one column pair per thread
             // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
-            static const bool generic = getenv("FOLVE_AMD_GENERIC_FFT") != nullptr;   // dev aid: compare the forms
-            if (pairs_ok && !generic && (f.cout == 1 || f.cout == 2) && (long long)njobs * max_blocks >= 256) {
-                static const char* rl = getenv("FOLVE_AMD_RUNLEN");
-                // the longest walk that still gives every CU a workgroup (measured at 64 streams x 32 blocks:
-                // 512 workgroups of 4 blocks 0.107 ms, 256 of 8 0.099, 128 of 16 0.172)
-                int runlen = rl ? atoi(rl) : 32;
-                while (!rl && runlen > 1 && (long long)njobs * ((max_blocks + runlen - 1) / runlen) < 256) runlen >>= 1;
+            const bool fast = tn.fft_form != 1 && pairs_ok && (f.cout == 1 || f.cout == 2) &&
+                              (tn.fft_form == 2 || (long long)njobs * max_blocks >= 256);
+            if (fast) {
+                const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
-                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2>), grid, block, 0, st, jobs, f, Y, runlen);
-                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1>), grid, block, 0, st, jobs, f, Y, runlen);
+                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true>), grid, block, 0, st, jobs, f, Y, runlen);
+                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1, true>), grid, block, 0, st, jobs, f, Y, runlen);
                 return hipGetLastError();
             }
         }
@@ -1013,13 +1220,18 @@ struct FilterLaunch {
 }  // namespace
 
 hipError_t launch_forward(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
-                          hipStream_t st) {
-    return dispatch_log2p<FwdLaunch>(f.log2P, jobs, njobs, max_blocks, f, pairs_ok, st);
+                          const Tuning& tn, hipStream_t st) {
+    return dispatch_log2p<FwdLaunch>(f.log2P, jobs, njobs, max_blocks, f, pairs_ok, tn, st);
 }
 
 hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
-                          bool walker_ok, hipStream_t st) {
-    return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, walker_ok, st);
+                          bool walker_ok, const Tuning& tn, hipStream_t st) {
+    return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, walker_ok, tn, st);
+}
+
+hipError_t launch_xlane_selftest(float* out512, hipStream_t st) {
+    hipLaunchKernelGGL(xlane_selftest_kernel, dim3(1), dim3(64), 0, st, out512);
+    return hipGetLastError();
 }
 
 hipError_t launch_filter_transform(const float* taps, float2* Htmp, float2* Gs, int ndata, int K, int log2P,
@@ -1095,40 +1307,44 @@ void fill_fft_tables(int log2P, float2* dst, int off[4]) {
     if (n[4]) fill_stage_b(dst + off[3], n[8]);
 }
 
-// Variant choice: the sliding-window kernel when the call carries >= 4 blocks per
-// stream (run-ahead batches); the generic kernel for short calls (a single block is
-// a pure stream over K rows and is already HBM-bound).  FOLVE_AMD_MAC=generic|s4|s8|s16|s32
-// overrides for experiments.
+// Form choice.  A single block per call is a pure stream over K rows (mac_kernel<1>, HBM-bound).
+// Run-ahead calls (>= 12 blocks): the whole-call walk when every output has one dense path of at
+// most 33 rows and the launch still fills the chip with one workgroup per (256 bins, output,
+// stream) — every X row read once; otherwise the 16-output sliding window, which also skips
+// unpopulated rows of sparse filters and splits long calls into time tiles for parallelism.
 hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, float2* Y, int time_tile,
-                      hipStream_t st) {
-    static const char* force = getenv("FOLVE_AMD_MAC");
+                      const MacShape& shape, const Tuning& tn, hipStream_t st) {
     const int P2 = f.P / 2;
-    int variant = 0, nb = 2, depth = 2;    // variant: 0 generic, else TT of the slide kernel
-    if (force && force[0] == 's') {
-        variant = atoi(force + 1);
-        if (strstr(force, "n1")) nb = 1;
-        const char* d = strchr(force, 'd');
-        if (d) depth = atoi(d + 1);
-    } else if (!force) {
-        if (time_tile >= 12) { variant = 16; nb = 1; depth = 4; }
-        else if (time_tile >= 6) { variant = 8; nb = 2; depth = 2; }
-        else if (time_tile >= 4) { variant = 4; nb = 2; depth = 2; }
+    int form = tn.mac_form;
+    const bool walk_ok = shape.single_path && f.K <= 33 && f.P >= 256;
+    if (form == 100 && !walk_ok) form = 0;
+    if (form == 0) {
+        if (time_tile >= 12) {
+            const long long wgs = (long long)njobs * f.cout * (f.P / 256);
+            form = (walk_ok && shape.dense && wgs >= 1024) ? 100 : 16;
+        } else if (time_tile >= 6) form = 8;
+        else if (time_tile >= 4) form = 4;
+        else form = 1;
     }
-    if (variant && f.P / nb < 64) variant = 0;
-    if (variant) {
-        const int pv = f.P / nb;
-        const int nt = pv < 256 ? pv : 256;
-        const int tiles = (max_blocks + variant - 1) / variant;
-        dim3 grid(pv / nt, f.cout * tiles, njobs), block(nt);
-#define FK_SLIDE(TTv, NBv, Dv)                                                                              \
-    if (variant == TTv && nb == NBv && depth == Dv) {                                                       \
-        hipLaunchKernelGGL((mac_slide_kernel<TTv, NBv, Dv>), grid, block, 0, st, jobs, f, Y, tiles);        \
-        return hipGetLastError();                                                                           \
+    if (form == 100) {
+        dim3 grid(f.P / 256, f.cout, njobs), block(256);
+        if (f.K <= 9) hipLaunchKernelGGL((mac_walk_kernel<9, 7>), grid, block, 0, st, jobs, f, Y);
+        else if (f.K <= 17) hipLaunchKernelGGL((mac_walk_kernel<17, 7>), grid, block, 0, st, jobs, f, Y);
+        else hipLaunchKernelGGL((mac_walk_kernel<33, 7>), grid, block, 0, st, jobs, f, Y);
+        return hipGetLastError();
     }
-        FK_SLIDE(4, 2, 2) FK_SLIDE(8, 2, 2) FK_SLIDE(8, 2, 4) FK_SLIDE(16, 2, 2) FK_SLIDE(16, 2, 4)
-        FK_SLIDE(16, 1, 2) FK_SLIDE(16, 1, 4) FK_SLIDE(32, 1, 2) FK_SLIDE(32, 1, 4) FK_SLIDE(8, 1, 4)
-#undef FK_SLIDE
-        return hipErrorInvalidValue;
+    if (form == 4 || form == 8 || form == 16) {
+        const int nb = form == 16 ? 1 : 2;
+        if (f.P / nb >= 64) {
+            const int pv = f.P / nb;
+            const int nt = pv < 256 ? pv : 256;
+            const int tiles = (max_blocks + form - 1) / form;
+            dim3 grid(pv / nt, f.cout * tiles, njobs), block(nt);
+            if (form == 16) hipLaunchKernelGGL((mac_slide_kernel<16, 1, 4>), grid, block, 0, st, jobs, f, Y, tiles);
+            else if (form == 8) hipLaunchKernelGGL((mac_slide_kernel<8, 2, 2>), grid, block, 0, st, jobs, f, Y, tiles);
+            else hipLaunchKernelGGL((mac_slide_kernel<4, 2, 2>), grid, block, 0, st, jobs, f, Y, tiles);
+            return hipGetLastError();
+        }
     }
     const int nt = P2 < 256 ? P2 : 256;
     int tt = 1;

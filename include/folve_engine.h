@@ -13,8 +13,11 @@
  * different threads; a committed filter is immutable and shareable.
  *
  * There is NO CPU fallback: without a usable HIP device every compute entry
- * point fails with FE_ERR_DEVICE.  After FE_ERR_DEVICE from a processing call the
- * convolver state of the streams in that call is undefined: reset or close them.
+ * point fails with FE_ERR_DEVICE.  A processing call that fails before its
+ * kernels were enqueued leaves its streams where they were; after a failure of the
+ * device itself (a kernel fault, a lost GPU) the convolver state of the streams in
+ * that call is undefined: reset or close them (folve::ProcessorPool::Return
+ * deletes such processors).
  */
 #ifndef FOLVE_ENGINE_H
 #define FOLVE_ENGINE_H
@@ -75,7 +78,10 @@ int fe_filter_create(fe_engine *e, int ninp, int nout, int maxsize, float densit
  * 203,252): ADDS data[k*step] at taps ind0+k; 0-based channels. */
 int fe_filter_add(fe_filter *f, int inp, int out, int step, const float *data, int ind0, int ind1);
 /* Convproc::impdata_copy(inp1, out1, inp2, out2) (zita-config.cc:274):
- * (inp2,out2) shares the spectra of (inp1,out1), later additions included. */
+ * (inp2,out2) shares the spectra of (inp1,out1), later additions to the source
+ * included (README.CONFIG.txt:91-97).  As in zita: returns 0 without linking when
+ * the source pair has no data yet or the target already has data of its own, and
+ * fe_filter_add on a linked target is a no-op. */
 int fe_filter_link(fe_filter *f, int inp1, int out1, int inp2, int out2);
 /* Transform the partitions on the GPU and make the filter immutable.  Until
  * then nothing touches the device (the loader is testable without a GPU). */
@@ -95,8 +101,17 @@ int fe_filter_get_taps(const fe_filter *f, int inp, int out, float *dst, int n);
 
 /* ---- stream: replaces Convproc's per-instance state ----------------------- */
 /* max_blocks_per_call bounds how many consecutive blocks one call may carry
- * (FDL ring = K-1+max_blocks rows per input channel); longer spans are split. */
+ * (FDL ring = K + max_blocks rows per input channel: the K + 1 rows of G reach K
+ * blocks back); longer spans are split. */
 int fe_stream_open(fe_filter *f, int max_blocks_per_call, fe_stream **out);
+/* Page-locked host memory for block buffers (what SoundProcessor's `buffer_`, sound-processor.cc:62,
+ * becomes), and its binding to a stream: host-pointer calls on that stream whose in/out lie inside
+ * the bound range are read and written by the kernels directly over the bus — no staging copies.
+ * The binding is a promise that the range stays allocated until it is unbound (buf = NULL) or the
+ * stream is closed.  In-place calls (in == out) are fine. */
+int fe_host_alloc(size_t bytes, void **out);
+void fe_host_free(void *p);
+int fe_stream_bind_host_buffer(fe_stream *s, void *buf, size_t bytes);
 /* Convproc::reset() (sound-processor.cc:140): zero all state, zero latency. */
 int fe_stream_reset(fe_stream *s);
 void fe_stream_close(fe_stream *s);
@@ -125,6 +140,22 @@ int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, c
 
 /* Running peaks of n streams with one synchronisation (what the batcher hands back per block). */
 int fe_batch_get_peaks(fe_stream *const *streams, int n, float *peak_signed, float *peak_abs);
+
+/* ---- launch-shape overrides (tests, experiments) ---------------------------- */
+/* The engine chooses kernel forms from the batch shape (walker run lengths so that every CU
+ * has two workgroups, the MAC form from blocks per call, ..).  A test pins a form on ONE
+ * engine to reach it with a small batch; 0 restores the automatic choice.  No process-wide
+ * state, no environment variables. */
+enum {
+    FE_TUNE_FWD_RUN = 0,   /* K1 walker: consecutive blocks per workgroup (1..4096) */
+    FE_TUNE_INV_RUN = 1,   /* K3 walker: consecutive blocks per workgroup */
+    FE_TUNE_MAC_FORM = 2,  /* K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk */
+    FE_TUNE_FFT_FORM = 3,  /* K1/K3: 1 general kernels only, 2 walkers whenever the shape allows */
+    FE_TUNE_FAIL_NEXT = 4  /* fault injection: the next launch round of this engine fails with FE_ERR_DEVICE */
+};
+int fe_engine_set_tuning(fe_engine *e, int knob, int value);
+/* Device self-test of the cross-lane exchange the FFT rows use (kernels.h launch_xlane_selftest). */
+int fe_debug_xlane(fe_engine *e, float *out512);
 
 /* ---- measurement hooks (bench.py: per-kernel HIP-event timing) ------------ */
 enum { FE_K_FORWARD = 0, FE_K_MAC = 1, FE_K_INVERSE = 2, FE_K_COUNT = 3 };

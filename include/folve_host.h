@@ -61,8 +61,9 @@ fh_processor *fh_pool_get_or_create(fh_pool *pool, const char *base_dir, int sam
 void fh_pool_return(fh_pool *pool, fh_processor *p);
 int fh_pool_pooled_count(fh_pool *pool, const char *config_path);
 
-/* run-ahead batcher (folve_amd/csrc/host/batch_scheduler.h): coalesce Process() calls of many file
- * threads into one GPU launch.  window_us / max_batch < 0 keep the current value. */
+/* the per-GPU combiner (folve_amd/csrc/host/batch_scheduler.h): Process() calls of many file threads
+ * that meet on a busy GPU leave as one launch; a lone call is never delayed.  On by default.
+ * window_us is ignored (there is no collection window); max_batch < 0 keeps the current value. */
 void fh_batching_set(int enabled, int window_us, int max_batch);
 int fh_batching_enabled(void);
 /* totals over all GPUs since process start */

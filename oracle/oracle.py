@@ -187,19 +187,35 @@ class SoundProcessor:
         assert n == x.shape[0]
         return out
 
-    def impulse(self, inp, out, ntaps=None):
-        """Recover the assembled float32 impulse response of path inp->out by
-        feeding a unit impulse (exact up to float32 FFT rounding)."""
-        raise NotImplementedError
-
     def __del__(self):
         if self.h:
             self.L.oc_sp_delete(self.h)
             self.h = None
 
 
-def bench_streams(nstreams, nblocks, nthreads, ninp=2, nout=2, size=262144, seed=3):
-    return lib().oc_bench_streams(nstreams, nblocks, nthreads, ninp, nout, size, seed)
+_NATIVE = None
+
+
+def native_bench_lib():
+    """liboracle_native.so: the same sources compiled -O3 -march=native on THIS machine (the box
+    whose cores are being timed); None if it cannot be built.  Only bench.py's cpu_baseline uses it."""
+    global _NATIVE
+    if _NATIVE is None:
+        so = os.path.join(_HERE, "liboracle_native.so")
+        try:
+            subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "native"], stdout=subprocess.DEVNULL)
+            L = C.CDLL(so)
+            L.oc_bench_streams.argtypes = [C.c_int] * 6 + [C.c_uint]
+            L.oc_bench_streams.restype = C.c_double
+            _NATIVE = L
+        except Exception:
+            _NATIVE = False
+    return _NATIVE or None
+
+
+def bench_streams(nstreams, nblocks, nthreads, ninp=2, nout=2, size=262144, seed=3, native=False):
+    L = (native_bench_lib() if native else None) or lib()
+    return L.oc_bench_streams(nstreams, nblocks, nthreads, ninp, nout, size, seed)
 
 
 # --------------------------------------------------------------------------

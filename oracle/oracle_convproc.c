@@ -119,7 +119,9 @@ int oc_impdata_create(oc_convproc *c, int inp, int out, int step,
     if (inp < 0 || inp >= c->ninp || out < 0 || out >= c->nout) return OC_BAD_PARAM;
     if (ind0 < 0 || ind1 < ind0) return OC_BAD_PARAM;
     oc_path *p = path_of(c, inp, out);
-    if (p->link) p = (oc_path *)resolve(p);   /* additions to a linked pair land in the shared data */
+    /* (zita, not in tree: Convlevel::impdata_write) a node that is a link takes no data of its
+     * own: the call returns without effect. */
+    if (p->link) return OC_OK;
     const int P = c->parsize;
     const float norm = 0.5f / (float)P;
     if (!p->fftb) {
@@ -155,12 +157,13 @@ int oc_impdata_copy(oc_convproc *c, int inp1, int out1, int inp2, int out2) {
     if (inp2 < 0 || inp2 >= c->ninp || out2 < 0 || out2 >= c->nout) return OC_BAD_PARAM;
     if (inp1 == inp2 && out1 == out2) return OC_BAD_PARAM;
     oc_path *src = path_of(c, inp1, out1), *dst = path_of(c, inp2, out2);
-    if (resolve(src) == dst) return OC_BAD_PARAM; /* would form a cycle */
-    if (dst->fftb) {
-        for (int k = 0; k < c->npar; ++k) free(dst->fftb[k]);
-        free(dst->fftb);
-        dst->fftb = NULL;
-    }
+    /* (zita, not in tree: Convlevel::impdata_copy)  M1 = findmacnode(inp1, out1, false);
+     * if (!M1) return;  M2 = findmacnode(inp2, out2, true);  if (M2->_fftb) return;
+     * M2->_link = M1;  — no source node yet, or a target that already has data: no effect. */
+    if (!src->used) return OC_OK;
+    if (dst->fftb) return OC_OK;
+    for (const oc_path *at = src; at; at = at->link)
+        if (at == dst) return OC_BAD_PARAM;       /* would form a cycle (undefined in zita) */
     dst->link = src;
     dst->used = 1;
     return OC_OK;

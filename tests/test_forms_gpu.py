@@ -1,0 +1,196 @@
+"""GPU: every kernel form the engine can choose, reached with small batches by pinning it
+(fe_engine_set_tuning), plus the benchmarked shape itself.
+
+The automatic choice depends on the batch shape — walker run lengths grow with the batch, the MAC
+form with the blocks per call — so without pinning a small test batch only ever sees run length 1
+and the general kernels.  Reference semantics under test: one block through the convolver,
+/root/reference/sound-processor.cc:98-127, evaluated many blocks and streams at a time.
+"""
+import numpy as np
+import pytest
+
+import folve_amd as fa
+from helpers import dense_taps, make_pair
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rms(a):
+    a = np.asarray(a, np.float64)
+    return float(np.sqrt(np.mean(a * a)))
+
+
+@pytest.fixture
+def tuned(engine):
+    """The session engine with every knob back on automatic afterwards."""
+    yield engine
+    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0)
+
+
+def test_xlane_exchange_semantics(engine):
+    """The cross-lane exchange the FFT rows rely on (fft_core.hpp xlane_*): v_permlane32_swap swaps
+    lanes 32..63 of its first operand with lanes 0..31 of its second, v_permlane16_swap the odd
+    16-lane rows of the first with the even rows of the second; together a 4 x 4 transpose between
+    lane row and register index."""
+    out = engine.xlane_selftest()
+    lane = np.arange(64)
+    a32, b32, a16, b16 = out[0:64], out[64:128], out[128:192], out[192:256]
+    assert np.array_equal(a32, np.where(lane < 32, lane, 100 + lane - 32))
+    assert np.array_equal(b32, np.where(lane < 32, lane + 32, 100 + lane))
+    odd = (lane // 16) % 2 == 1
+    assert np.array_equal(a16, np.where(odd, 100 + lane - 16, lane))
+    assert np.array_equal(b16, np.where(odd, 100 + lane, lane + 16))
+    for i in range(4):                       # lane row a, register i <- lane row i, register a
+        assert np.array_equal(out[256 + 64 * i:320 + 64 * i], 10 * (lane // 16) + i)
+
+
+@pytest.mark.parametrize("runlen", [2, 4, 8, 16, 32])
+@pytest.mark.parametrize("channels", [2, 1])
+def test_walkers_at_every_run_length(tuned, oracle, runlen, channels):
+    """forward_walker<13> / inverse_walker<13, 1|2> with multi-block walks: the block-to-block carry of
+    the prefetched PCM quads and Y rows, the peeled short last block after a walk, and a walk that ends
+    inside a stream (blocks not a multiple of the run length)."""
+    size = 20000                                                       # P = 8192, K = 3
+    rng = np.random.default_rng(1000 * runlen + channels)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(channels)}
+    if channels == 2:
+        paths[(1, 0)] = [(11, (rng.standard_normal(5000) * 0.01).astype(np.float32))]
+    sp, flt, _ = make_pair(tuned, oracle, channels, channels, size, paths)
+    P = flt.block_size
+    nblocks = 2 * runlen + 3
+    lens = [nblocks * P, nblocks * P - 4321, (nblocks - 1) * P - 7, (runlen + 1) * P]
+    xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
+    hd = dense_taps(paths, size)
+
+    tuned.set_tuning(fft_form=2, fwd_run=runlen, inv_run=runlen)
+    walk = [flt.open_stream(nblocks) for _ in lens]
+    ys = fa.batch_process(walk, xs)
+    more = [rng.uniform(-1, 1, (2 * P + 9, channels)).astype(np.float32) for _ in lens]
+    ys2 = fa.batch_process(walk, more)                                 # state carried across walker calls
+    tuned.set_tuning(fft_form=1)
+    gen = [flt.open_stream(nblocks) for _ in lens]
+    yg = fa.batch_process(gen, xs)                                     # the general kernels on the same input
+    for s in range(len(lens)):
+        assert _rms(ys[s] - yg[s]) <= 2e-6, s
+        y64 = oracle.linear_convolution_f64(xs[s], hd, channels)
+        assert _rms(ys[s] - y64) <= TOL and _rms(ys[s] - y64) / _rms(y64) <= TOL, s
+    for s in (0, 1):
+        sp.reset()
+        assert _rms(ys[s] - sp.run(xs[s])) <= TOL
+        pad = (-lens[s]) % P
+        full = oracle.linear_convolution_f64(np.concatenate([np.pad(xs[s], ((0, pad), (0, 0))), more[s]]), hd, channels)
+        assert _rms(ys2[s] - full[lens[s] + pad:]) <= TOL
+        both = np.concatenate([ys[s], ys2[s]])
+        pk = walk[s].peaks()
+        assert abs(pk[0] - max(0.0, float(both.max()))) <= 1e-6 and abs(pk[1] - float(np.abs(both).max())) <= 1e-6
+
+
+@pytest.mark.parametrize("size,cross", [
+    (262144, False),      # K = 32: 33 rows of G, mac_walk<33>
+    (131072, False),      # K = 16: mac_walk<17>
+    (65536, False),       # K = 8:  mac_walk<9>
+    (50000, True),        # two paths into one output: the walk does not apply, the pin falls back
+    (204800, False),      # K = 25 with a sparse path (echo-like): rows of zeros
+])
+def test_mac_forms_agree(tuned, oracle, size, cross):
+    """K2 in all its forms on the same call: general (1), sliding windows of 4 / 8 / 16 outputs, and
+    the whole-call walk (100).  29 blocks: not a multiple of any tile, shorter than the walk's window."""
+    rng = np.random.default_rng(size)
+    if size == 204800:
+        paths = {(0, 0): [(0, np.float32([0.7])), (22050, np.float32([0.3]))],
+                 (1, 1): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))]}
+    else:
+        paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    if cross:
+        paths[(0, 1)] = [(3, (rng.standard_normal(size // 2) * 0.01).astype(np.float32))]
+    sp, flt, _ = make_pair(tuned, oracle, 2, 2, size, paths)
+    P, T, S = flt.block_size, 29, 5
+    lens = [T * P - 1000 * s for s in range(S)]
+    xs = [rng.uniform(-1, 1, (n, 2)).astype(np.float32) for n in lens]
+    more = [rng.uniform(-1, 1, (45 * P - 3, 2)).astype(np.float32) for _ in range(S)]     # longer than the window ring
+    hd = dense_taps(paths, size)
+    results = {}
+    for form in (1, 4, 8, 16, 100):
+        tuned.set_tuning(mac_form=form)
+        st = [flt.open_stream(48) for _ in range(S)]
+        y1 = fa.batch_process(st, xs)
+        y2 = fa.batch_process(st, more)                               # history rows come from the first call
+        results[form] = (y1, y2)
+    for form in (4, 8, 16, 100):
+        for s in range(S):
+            assert _rms(results[form][0][s] - results[1][0][s]) <= 2e-6, (form, s)
+            assert _rms(results[form][1][s] - results[1][1][s]) <= 2e-6, (form, s)
+    for s in (0, S - 1):
+        y64 = oracle.linear_convolution_f64(xs[s], hd, 2)
+        pad = (-lens[s]) % P
+        full = oracle.linear_convolution_f64(np.concatenate([np.pad(xs[s], ((0, pad), (0, 0))), more[s]]), hd, 2)
+        for form in (1, 16, 100):
+            y1, y2 = results[form]
+            assert _rms(y1[s] - y64) <= TOL and _rms(y1[s] - y64) / _rms(y64) <= TOL, (form, s)
+            assert _rms(y2[s] - full[lens[s] + pad:]) <= TOL, (form, s)
+
+
+def test_benchmarked_shape_parity(engine, oracle):
+    """bench.py's workload, kernel for kernel: 64 streams x 2 channels x 64 blocks per call through a
+    262 144-tap 2-path filter, streams opened for 64-block calls, device-resident PCM, automatic form
+    choice (walker run length 8, the whole-call MAC walk).  Some ragged tails; a second call carries
+    the state.  Checked streams: against the float64 convolution (absolute and relative) and against
+    the oracle."""
+    torch = pytest.importorskip("torch")
+    S, T, C, size = 64, 64, 2, 262144
+    rng = np.random.default_rng(3)
+    paths = {}
+    for c in range(C):
+        h = rng.standard_normal(size).astype(np.float32)
+        paths[(c, c)] = [(0, h / np.linalg.norm(h))]
+    sp, flt, _ = make_pair(engine, oracle, C, C, size, paths)
+    P = flt.block_size
+    lens = [T * P - (0 if s % 5 else 777 + 8 * s) for s in range(S)]
+    check = (0, 5, 63)                                              # 0 and 5 are ragged, 63 whole
+    xs = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
+    ys = [torch.zeros(T * P, C, device="cuda") for _ in range(S)]
+    streams = [flt.open_stream(T) for _ in range(S)]
+    from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS
+    BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], lens, FE_DEVICE_PTRS).run()
+    x2 = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
+    y2 = [torch.zeros(T * P, C, device="cuda") for _ in range(S)]
+    BatchPlan(streams, [x.data_ptr() for x in x2], [y.data_ptr() for y in y2], [T * P] * S, FE_DEVICE_PTRS).run()
+    hd = dense_taps(paths, size)
+    for s in check:
+        x = xs[s].cpu().numpy()[:lens[s]]
+        y = ys[s].cpu().numpy()[:lens[s]]
+        y64 = oracle.linear_convolution_f64(x, hd, C)
+        assert _rms(y - y64) <= TOL and _rms(y - y64) / _rms(y64) <= TOL, s
+        sp.reset()
+        yo = sp.run(x)
+        assert _rms(y - yo) <= TOL and _rms(y - yo) / _rms(yo) <= TOL, s
+        pad = (-lens[s]) % P
+        xx = np.concatenate([np.pad(x, ((0, pad), (0, 0))), x2[s].cpu().numpy()])
+        full = oracle.linear_convolution_f64(xx, hd, C)
+        second = y2[s].cpu().numpy()
+        assert _rms(second - full[lens[s] + pad:]) <= TOL, s
+    # blocks past a ragged tail were never written
+    assert float(ys[0][lens[0]:].abs().max()) == 0.0
+
+
+def test_injected_failure_leaves_stream_state(tuned, oracle):
+    """A launch round that fails before its kernels are enqueued (fault injection) reports
+    FE_ERR_DEVICE and leaves the stream where it was: the same block then processes as if the failed
+    call had never happened."""
+    rng = np.random.default_rng(5)
+    size = 20000
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    _, flt, st = make_pair(tuned, oracle, 2, 2, size, paths, max_blocks=4)
+    P = flt.block_size
+    x = rng.uniform(-1, 1, (3 * P, 2)).astype(np.float32)
+    y_a = st.process_blocks(x[:P])
+    done = st.blocks_done()
+    tuned.set_tuning(fail_next=1)
+    with pytest.raises(fa.FolveError) as err:
+        st.process_blocks(x[P:2 * P])
+    assert err.value.code == -4 and "injected" in str(err.value)
+    assert st.blocks_done() == done
+    y_b = st.process_blocks(x[P:])
+    ref = flt.open_stream(4).process_blocks(x)
+    assert np.array_equal(np.concatenate([y_a, y_b]), ref)

@@ -75,9 +75,36 @@ def test_filter_limits_and_block_size():
         f.add(64, 0, [1.0])
     with pytest.raises(fa.FolveError):
         f.link(0, 0, 0, 0)
-    f.link(0, 0, 1, 1)
+    f.add(0, 0, [1.0])
+    f.link(0, 0, 1, 1)                  # (1,1) -> (0,0)
+    f.link(1, 1, 2, 2)                  # (2,2) -> (1,1) -> (0,0)
     with pytest.raises(fa.FolveError):
-        f.link(1, 1, 0, 0)              # cycle
+        f.link(2, 2, 1, 1)              # (1,1) -> (2,2) -> (1,1): a cycle
+
+
+def test_link_ordering_follows_zita(oracle):
+    """Convproc::impdata_copy as zita implements it (zita-config.cc:274 is the call site): no effect when
+    the source pair has no data yet or the target already has data; a linked target ignores data added
+    to it; data added to the source afterwards is shared.  Engine and oracle restate the same rules."""
+    f = fa.Filter(None, 2, 2, 1000)
+    c = oracle.Convproc(2, 2, 1000)
+    f.link(0, 0, 0, 1); c.impdata_copy(0, 0, 0, 1)      # copy BEFORE the source has data: nothing happens
+    f.add(0, 0, [1.0, 2.0]); c.impdata_create(0, 0, np.float32([1.0, 2.0]), 0)
+    assert f.path_partitions(0, 1) == 0 and c.path_partitions(0, 1) == 0
+    f.add(1, 1, [5.0]); c.impdata_create(1, 1, np.float32([5.0]), 0)
+    f.link(0, 0, 1, 1); c.impdata_copy(0, 0, 1, 1)      # target has data of its own: nothing happens
+    assert f.taps(1, 1, 4).tolist() == [5.0, 0, 0, 0]
+    f.link(0, 0, 1, 0); c.impdata_copy(0, 0, 1, 0)      # a real link
+    f.add(1, 0, [9.0]); c.impdata_create(1, 0, np.float32([9.0]), 0)         # ignored: (1,0) is a link
+    f.add(0, 0, [0.5], 2); c.impdata_create(0, 0, np.float32([0.5]), 2)      # seen through the link
+    assert f.taps(1, 0, 4).tolist() == [1.0, 2.0, 0.5, 0] and f.taps(0, 0, 4).tolist() == [1.0, 2.0, 0.5, 0]
+    assert c.path_partitions(1, 0) == 1 and f.path_partitions(1, 0) == 1
+    # the oracle's spectra agree: an impulse through (1 -> 0) returns the shared taps
+    sp = oracle.SoundProcessor.wrap(c)
+    x = np.zeros((sp.fragm, 2), np.float32)
+    x[0, 1] = 1.0
+    y = sp.run(x)
+    assert np.allclose(y[:4, 0], [1.0, 2.0, 0.5, 0], atol=1e-6) and np.allclose(y[:2, 1], [5.0, 0.0], atol=1e-6)
 
 
 def test_accumulate_link_and_masks():
@@ -87,7 +114,8 @@ def test_accumulate_link_and_masks():
     f.add(0, 0, [9.0], 29999)
     f.add(0, 0, [7.0, 7.0, 7.0], 32767)                 # beyond K*P = 32768: clipped
     f.link(0, 0, 1, 1)
-    f.add(1, 1, [0.5], 0)                               # addition through the link lands in the shared data
+    f.add(1, 1, [0.25], 0)                              # a linked pair takes no data of its own (zita): no effect
+    f.add(0, 0, [0.5], 0)                               # a later addition to the SOURCE is shared (README.CONFIG.txt:91-97)
     t = f.taps(0, 0)
     assert t[8190] == 1 and t[8192] == 3 and t[8197] == 1 and t[29999] == 9 and t[32767] == 7 and t[0] == 0.5
     assert np.array_equal(f.taps(1, 1), t)

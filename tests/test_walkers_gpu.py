@@ -88,41 +88,6 @@ def test_unaligned_device_pointers_fall_back_to_general_kernels(engine, oracle):
     assert _rms(yu[3] - y64u) <= TOL
 
 
-def test_two_lane_fork_matches_single_lane(oracle):
-    """FOLVE_AMD_LANES=2: a large batch forks half of its streams onto a second HIP stream (one kernel
-    behind the first half) and joins again.  The halves are smaller launches, so they may take the
-    general kernels where the whole batch takes the walkers: equal to rounding, not bit for bit."""
-    import os
-    rng = np.random.default_rng(17)
-    size, S, T = 20000, 24, 12
-    taps = [(rng.standard_normal(size) / np.sqrt(size)).astype(np.float32) for _ in range(2)]
-    xs = [rng.uniform(-1, 1, (T * 8192 - 7 * s, 2)).astype(np.float32) for s in range(S)]
-
-    def run(lanes):
-        old = os.environ.get("FOLVE_AMD_LANES")
-        os.environ["FOLVE_AMD_LANES"] = str(lanes)
-        try:
-            eng = fa.Engine(0)
-        finally:
-            if old is None:
-                os.environ.pop("FOLVE_AMD_LANES", None)
-            else:
-                os.environ["FOLVE_AMD_LANES"] = old
-        flt = fa.Filter(eng, 2, 2, size)
-        for c in range(2):
-            flt.add(c, c, taps[c])
-        flt.commit()
-        streams = [flt.open_stream(T) for _ in range(S)]
-        first = fa.batch_process(streams, xs)
-        second = fa.batch_process(streams, [x[: 3 * 8192] for x in xs])      # state carried across forked calls
-        return first, second
-
-    a1, a2 = run(1)
-    b1, b2 = run(2)                     # S * T * 2 = 576 block-channels >= the 512-unit fork threshold
-    for x, y in zip(a1 + a2, b1 + b2):
-        assert np.abs(x - y).max() <= 2e-6
-
-
 def test_pipelined_host_batch_mixed_filters_and_rounds(engine, oracle):
     """A host-pointer batch above 16 MB is cut into chunks of streams that ride the bus in, compute
     and ride out on three HIP streams (engine.cpp run_pipelined).  Streams of two filters interleaved,
