@@ -77,6 +77,11 @@ void DeviceRouter::StreamClosed(fe_engine* e) {
     for (Slot& s : slots_) if (s.engine == e && s.live > 0) s.live--;
 }
 
+int DeviceRouter::cached_filters() const {
+    std::lock_guard<std::mutex> lk(mu_);
+    return static_cast<int>(filters_.size());
+}
+
 int DeviceRouter::live_streams(int slot) const {
     std::lock_guard<std::mutex> lk(mu_);
     return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)].live : 0;
@@ -86,7 +91,7 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
                                    int channels, ZitaConfig* out_cfg) {
     // Serialised like the reference serialises Create() (sound-processor.cc:43).
     std::lock_guard<std::mutex> lk(mu_);
-    const std::pair<std::string, int> key(config_file, fe_engine_device(engine));
+    const std::pair<std::string, fe_engine*> key(config_file, engine);
     auto it = filters_.find(key);
     if (it != filters_.end()) {
         if (it->second.mtime == mtime) {
@@ -111,7 +116,7 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
         return NULL;
     }
     if (fe_filter_commit(zita.filter) != 0) {
-        Logf("Cannot transform filter %s on GPU %d: %s", config_file.c_str(), key.second, fe_last_error());
+        Logf("Cannot transform filter %s on GPU %d: %s", config_file.c_str(), fe_engine_device(engine), fe_last_error());
         fe_filter_release(zita.filter);
         return NULL;
     }

@@ -4,7 +4,7 @@
 // the multi-GPU form of the pool is "pick a GPU per new processor, keep it there"
 // (SURVEY.md §8e).  One engine per visible device, created lazily; a new stream
 // goes to the device with the fewest live streams.  Committed filters are cached
-// per (config path, mtime, device) so that all streams of one configuration on a
+// per (config path, mtime, slot) so that all streams of one configuration on a
 // GPU share a single set of spectra — which is also what lets them be batched.
 #pragma once
 
@@ -34,6 +34,7 @@ public:
     void StreamOpened(fe_engine* e);
     void StreamClosed(fe_engine* e);
     int live_streams(int slot) const;
+    int cached_filters() const;                // committed filters held: one per (configuration, slot) in use
 
     // Parsed + committed filter for (config, mtime) on `engine`; NULL if the
     // configuration is broken.  The caller gets its own reference.
@@ -45,7 +46,7 @@ private:
     struct CachedFilter { fe_filter* filter; ZitaConfig cfg; time_t mtime; };
     mutable std::mutex mu_;
     std::vector<Slot> slots_;
-    std::map<std::pair<std::string, int>, CachedFilter> filters_;   // (config path, device) -> filter
+    std::map<std::pair<std::string, fe_engine*>, CachedFilter> filters_;   // (config path, engine of a slot) -> filter
 };
 
 }  // namespace folve

@@ -101,6 +101,8 @@ long long fh_processor_config_file_timestamp(const fh_processor* p) { return SP(
 int fh_processor_config_still_up_to_date(const fh_processor* p) { return SP(p)->ConfigStillUpToDate(); }
 int fh_processor_device(const fh_processor* p) { return SP(p)->device(); }
 fe_stream* fh_processor_stream(const fh_processor* p) { return SP(p)->stream(); }
+fe_engine* fh_processor_engine(const fh_processor* p) { return SP(p)->engine(); }
+int fh_processor_ok(const fh_processor* p) { return SP(p)->ok() ? 1 : 0; }
 
 fh_pool* fh_pool_create(int max_per_config) { return reinterpret_cast<fh_pool*>(new ProcessorPool(max_per_config)); }
 void fh_pool_destroy(fh_pool* pool) { delete PP(pool); }
@@ -142,5 +144,6 @@ void fh_batching_stats(long long* requests, long long* batches, long long* large
 
 int fh_router_device_count(void) { return folve::DeviceRouter::Default()->device_count(); }
 int fh_router_live_streams(int slot) { return folve::DeviceRouter::Default()->live_streams(slot); }
+int fh_router_cached_filters(void) { return folve::DeviceRouter::Default()->cached_filters(); }
 
 }  // extern "C"

@@ -82,6 +82,7 @@ public:
 
     int block_size() const { return zita_config_.fragm; }
     fe_stream* stream() const { return stream_; }      // for batched submission
+    fe_engine* engine() const { return zita_config_.engine; }
     int device() const;
     bool ok() const { return ok_; }                     // false after an engine failure
 

@@ -27,6 +27,9 @@ HOST_SYMBOLS = [
     ("fh_processor_config_still_up_to_date", _i, [_vp]),
     ("fh_processor_device", _i, [_vp]),
     ("fh_processor_stream", _vp, [_vp]),
+    ("fh_router_cached_filters", _i, []),
+    ("fh_processor_engine", _vp, [_vp]),
+    ("fh_processor_ok", _i, [_vp]),
     ("fh_pool_create", _vp, [_i]),
     ("fh_pool_destroy", None, [_vp]),
     ("fh_pool_get_or_create", _vp, [_vp, C.c_char_p, _i, _i, _i, C.c_char_p, _i]),

@@ -50,6 +50,8 @@ long long fh_processor_config_file_timestamp(const fh_processor *p);
 int fh_processor_config_still_up_to_date(const fh_processor *p);
 int fh_processor_device(const fh_processor *p);
 fe_stream *fh_processor_stream(const fh_processor *p);
+fe_engine *fh_processor_engine(const fh_processor *p);
+int fh_processor_ok(const fh_processor *p);            /* 0 after an engine failure (the pool discards it) */
 
 /* processor-pool.cc:33 ProcessorPool(max_per_config) */
 fh_pool *fh_pool_create(int max_per_config);
@@ -72,6 +74,7 @@ void fh_batching_stats(long long *requests, long long *batches, long long *large
 /* the process-wide GPU sharder */
 int fh_router_device_count(void);
 int fh_router_live_streams(int slot);
+int fh_router_cached_filters(void);                     /* committed filters held: one per (configuration, slot) in use */
 
 #ifdef __cplusplus
 }

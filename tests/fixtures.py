@@ -14,6 +14,9 @@ def write_wav(path, data, rate=44100, fmt="pcm16"):
     if data.ndim == 1:
         data = data[:, None]
     ch = data.shape[1]
+    fmt_ext = fmt.startswith("wavex-")              # "wavex-pcm24": the same samples in a WAVE_FORMAT_EXTENSIBLE file
+    if fmt_ext:
+        fmt = fmt[6:]
     if fmt == "pcm16":
         raw, tag, bits = data.astype("<i2").tobytes(), 1, 16
     elif fmt == "pcm24":
@@ -29,6 +32,14 @@ def write_wav(path, data, rate=44100, fmt="pcm16"):
     else:
         raise ValueError(fmt)
     align = ch * bits // 8
+    if fmt_ext:
+        # WAVE_FORMAT_EXTENSIBLE: 40-byte fmt chunk, the real format tag is the first word of the sub-format GUID
+        guid = struct.pack("<H", tag) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+        hdr = struct.pack("<4sI4s4sIHHIIHHHHI", b"RIFF", 60 + len(raw), b"WAVE", b"fmt ", 40, 0xFFFE, ch, rate,
+                          rate * align, align, bits, 22, bits, (1 << ch) - 1) + guid + struct.pack("<4sI", b"data", len(raw))
+        with open(path, "wb") as f:
+            f.write(hdr + raw)
+        return
     hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(raw), b"WAVE", b"fmt ", 16, tag, ch, rate,
                       rate * align, align, bits, b"data", len(raw))
     with open(path, "wb") as f:

@@ -183,7 +183,8 @@ def test_processors_run_concurrently_from_threads(oracle, tmp_path):
 
 
 def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
-    """folve::BatchScheduler: Process() calls of many file threads become one GPU launch (SURVEY §8f-2)."""
+    """folve::BatchScheduler: Process() calls of many file threads that meet on a busy GPU leave as one
+    launch; there is no timer — a lone call is never delayed (see the latency test)."""
     d, hs = make_santalucia_shaped_dir(tmp_path)
     conf = os.path.join(d, "filter-44100.conf")
     sigs = [seeded_input(70 + i, 5 * 8192 + 64 * i, 2) for i in range(12)]
@@ -196,13 +197,13 @@ def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
         [t.join() for t in th]
         return outs, [p.max_output_value() for p in procs]
 
-    plain, peaks_plain = run_all()
-    before = H.batching_stats()
-    H.set_batching(True, window_us=2000, max_batch=64)
+    H.set_batching(False)                                          # every block launched by itself
     try:
-        batched, peaks_batched = run_all()
+        plain, peaks_plain = run_all()
     finally:
-        H.set_batching(False)
+        H.set_batching(True, max_batch=64)                         # the default: blocks that meet on a busy GPU share a launch
+    before = H.batching_stats()
+    batched, peaks_batched = run_all()
     after = H.batching_stats()
     nreq = after["requests"] - before["requests"]
     nbat = after["batches"] - before["batches"]
@@ -215,7 +216,7 @@ def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
 
 
 def test_pool_churn_under_threads_with_two_filters_and_batching(oracle, tmp_path):
-    """Open/return/reuse churn from several threads, two configurations at once, batcher on."""
+    """Open/return/reuse churn from several threads, two configurations at once, through the combiner."""
     d_echo = make_echo_filter_dir(tmp_path)
     d_low = make_pass_filter_dir(tmp_path, "lowpass")
     pool = H.ProcessorPool(3)
@@ -245,13 +246,118 @@ def test_pool_churn_under_threads_with_two_filters_and_batching(oracle, tmp_path
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
 
-    H.set_batching(True, window_us=300, max_batch=32)
-    try:
-        th = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-    finally:
-        H.set_batching(False)
+    assert H._L().fh_batching_enabled() == 1                       # on by default
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
     assert not errors, errors
     assert pool.pooled_count(os.path.join(d_echo, "filter-44100.conf")) <= 3
     assert pool.pooled_count(os.path.join(d_low, "filter-44100.conf")) <= 3
+
+
+def test_hilbert_copy_cd_and_wavex_through_the_gpu(oracle, tmp_path):
+    """/impulse/hilbert (zita-config.cc:212-259), /impulse/copy (cc:262-279), /cd and a 24-bit
+    WAVE_FORMAT_EXTENSIBLE impulse file (zita-audiofile.cc:63-92), loaded by SoundProcessor::Create and run
+    on the GPU: equal to the oracle's loader + convolver and to the float64 convolution of the taps the
+    configuration describes."""
+    sub = os.path.join(str(tmp_path), "ir dir")
+    os.makedirs(sub)
+    rng = np.random.default_rng(41)
+    ir = rng.uniform(-0.5, 0.5, (5000, 2))
+    from fixtures import write_wav
+    write_wav(os.path.join(sub, "x24.wav"), ir, 44100, "wavex-pcm24")
+    conf = os.path.join(str(tmp_path), "filter-44100.conf")
+    with open(conf, "w") as f:
+        f.write("# hilbert pair + shared room response\n"
+                "/convolver/new 2 3 512 20000 0.3\n"
+                "/cd \"ir dir\"\n"
+                "/impulse/read 1 1 0.5 40 0 0 1 x24.wav\n"
+                "/impulse/read 2 2 0.25 0 1000 3000 2 'x24.wav'\n"
+                "/impulse/hilbert 1 2 0.9 4096 8190\n"          # spans the first partition boundary
+                "/impulse/hilbert 2 1 0.6 300 256\n"
+                "/impulse/dirac 2 1 0.2 19999\n"                 # accumulates onto the hilbert pair's last tap
+                "/impulse/copy 1 3 1 1\n"                        # output 3 shares (1 -> 1) ...
+                "/impulse/read 1 1 0.125 8000 0 100 2 x24.wav\n"  # ... including this later addition
+                "/impulse/copy 2 3 2 1\n")
+    p24 = (np.clip(np.round(ir * 8388608.0), -8388608, 8388607).astype(np.int32) * 256).astype(np.float32) / np.float32(2147483648.0)
+    size = 20000
+    h = {k: np.zeros(size, np.float32) for k in [(0, 0), (1, 1), (0, 1), (1, 0)]}
+    h[(0, 0)][40:5040] += p24[:, 0] * np.float32(0.5)
+    h[(0, 0)][8000:8100] += p24[:100, 1] * np.float32(0.125)
+    h[(1, 1)][0:3000] += p24[1000:4000, 1] * np.float32(0.25)
+
+    def hilbert(gain, delay, length):                                # zita-config.cc:239-250, float32 as there
+        out = np.zeros(size, np.float32)
+        hh = length // 2
+        g = np.float32(gain) * np.float32(2.0 / np.pi)
+        taps = np.zeros(length, np.float32)
+        for i in range(1, hh, 2):
+            v = g / np.float32(i) * (np.float32(0.43) + np.float32(0.57) * np.cos(np.float32(i) * np.float32(np.pi) / np.float32(hh), dtype=np.float32))
+            taps[hh + i] = -v
+            taps[hh - i] = v
+        out[delay - hh:delay - hh + length] = taps
+        return out
+
+    h[(0, 1)] += hilbert(0.9, 4096, 8190)
+    h[(1, 0)] += hilbert(0.6, 300, 256)
+    h[(1, 0)][19999] += np.float32(0.2)
+    h[(0, 2)] = h[(0, 0)]
+    h[(1, 2)] = h[(1, 0)]
+
+    sp = H.SoundProcessor.create(conf, 44100, 2)
+    osp = oracle.SoundProcessor.create(conf, 44100, 2)
+    assert sp is not None and osp is not None and sp.ninp == 2 and sp.nout == 3 and sp.fragm == 8192
+    x = seeded_input(77, 5 * 8192 + 1234, 2)
+    y = sp.run(x)
+    yo = osp.run(x)
+    y64 = oracle.linear_convolution_f64(x, h, 3)
+    assert oracle.rms(y - yo) <= TOL
+    assert oracle.rms(y - y64) <= TOL and oracle.rms(y - y64) / oracle.rms(y64) <= TOL
+    assert oracle.rms(y[:, 2]) > 0.01                                                        # output 3 is fed through the copies
+    assert sp.max_output_value() == pytest.approx(max(0.0, float(y.max())), abs=1e-6)
+    assert sp.max_abs_output_value() == pytest.approx(float(np.abs(y).max()), abs=1e-6)
+
+
+def test_failed_processor_is_not_pooled(oracle, tmp_path):
+    """After an engine failure the convolver state of a processor is undefined (folve_engine.h); the
+    reference has no such case, and the pool must not hand that processor to the next file
+    (processor-pool.cc:93-118 is where it would be re-pooled)."""
+    import ctypes as C
+    import folve_amd as fa
+    d = make_echo_filter_dir(tmp_path)
+    conf = os.path.join(d, "filter-44100.conf")
+    pool = H.ProcessorPool(3)
+    good, _ = pool.get_or_create(d, 44100, 2, 16)
+    bad, _ = pool.get_or_create(d, 44100, 2, 16)
+    x = seeded_input(3, 8192, 2)
+    y = good.run(x)
+    L = fa.lib()
+    L.fh_processor_engine.restype = C.c_void_p
+    L.fh_processor_engine.argtypes = [C.c_void_p]
+    eng = L.fh_processor_engine(bad.h)
+    assert L.fe_engine_set_tuning(C.c_void_p(eng), 4, 1) == 0       # FE_TUNE_FAIL_NEXT
+    z = bad.run(x)                                                   # the block fails on the "device"
+    assert not z.any() and L.fh_processor_ok(bad.h) == 0             # zeros out, as documented
+    pool.give_back(bad)
+    assert pool.pooled_count(conf) == 0                              # discarded, not pooled
+    pool.give_back(good)
+    assert pool.pooled_count(conf) == 1
+    again, _ = pool.get_or_create(d, 44100, 2, 16)
+    assert again.h == good.h and np.array_equal(again.run(x), y)
+
+
+def test_single_block_latency_and_zero_copy(oracle, tmp_path):
+    """SoundProcessor::Process is one synchronous 8192-frame block (sound-processor.cc:98-127).  Its block
+    buffer is page-locked memory bound to the stream, so the kernels read and write it directly: the call
+    is three launches and one wait.  Bounds the cost loosely (the bench line reports the number)."""
+    import time as _t
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    sp = H.SoundProcessor.create(os.path.join(d, "filter-44100.conf"), 44100, 2)
+    x = seeded_input(5, 40 * 8192, 2)
+    y = sp.run(x[:8 * 8192])                                         # warm
+    t0 = _t.perf_counter()
+    y2 = sp.run(x[8 * 8192:])
+    dt = (_t.perf_counter() - t0) / 32
+    full = oracle.linear_convolution_f64(x, hs, 2)
+    assert oracle.rms(np.concatenate([y, y2]) - full) <= TOL
+    assert dt < 500e-6, dt                                           # per block, Python loop included

@@ -1,0 +1,51 @@
+"""GPU: the multi-GPU code paths on a one-GPU box.
+
+(a) The in-process sharder (folve::DeviceRouter under ProcessorPool, the reference's
+    processor-pool.cc:48-91 plus "which GPU") with TWO slots — both on device 0, which exercises
+    everything except a second physical GPU: least-loaded placement, one engine and one committed
+    filter per (configuration, slot), the per-slot combiner, parity.
+(b) bench.py's N = 2 path under torch.distributed.run (gloo, both ranks on device 0): sharding by
+    stream index, max-over-ranks timing, one JSON line from rank 0.
+Both run in fresh subprocesses: FOLVE_AMD_DEVICES is read once per process, and the parent must not
+have touched the GPU for the launcher's children."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_router_slots_share_the_load(tmp_path):
+    env = dict(os.environ, FOLVE_AMD_DEVICES="0,0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "router_worker.py"), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("ROUTER_JSON ")][-1]
+    out = json.loads(line[len("ROUTER_JSON "):])
+    assert out["slots"] == 2 and out["engines"] == 2
+    assert out["live_while_held"] == [4, 4] and out["per_engine"] == [4, 4]     # least-loaded placement alternates
+    assert out["cached_filters"] == 2                                           # one committed filter per (config, slot)
+    assert out["max_rms"] <= 1e-5
+    assert out["pooled"] == 8
+    assert all(abs(a - b) <= 1 for a, b in out["placement_steps"])              # never more than one apart while filling
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                           # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
+    assert out["config"]["streams_per_gpu"] == 8 and out["config"]["total_streams"] == 16
+    assert out["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]   # gpu = stream mod N
+    assert out["parity_rms"] is not None and out["parity_rms"] <= 1e-5
+    assert out["value"] > 0

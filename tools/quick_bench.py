@@ -12,6 +12,8 @@ size = 262144
 P = 8192
 ts = torch.cuda.Stream()
 eng = fa.Engine(0, ts.cuda_stream)
+if os.environ.get("QB_TUNE"):                    # e.g. QB_TUNE=mac_form=16,fwd_run=8
+    eng.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["QB_TUNE"].split(","))})
 rng = np.random.default_rng(3)
 flt = fa.Filter(eng, 2, 2, size)
 for c in range(2):

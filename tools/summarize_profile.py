@@ -18,8 +18,8 @@ res = {"kernel_trace": {}, "kernel_stats": {}, "pmc": {}}
 
 
 def short(name):
-    for k in ("forward_dual_kernel", "make_g_kernel", "forward_walker_kernel", "inverse_walker_kernel", "mac_slide_kernel", "forward_kernel", "mac_kernel",
-              "inverse_kernel", "filter_kernel"):
+    for k in ("forward_dual_kernel", "make_g_kernel", "forward_walker_kernel", "inverse_walker_kernel", "mac_slide_kernel", "mac_walk_kernel",
+              "forward_kernel", "mac_kernel", "inverse_kernel", "filter_kernel"):
         if k in name:
             t = name.split(k)[1].split(">")[0].strip("<")
             return "%s<%s>" % (k, t)
