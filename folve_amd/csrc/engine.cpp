@@ -68,6 +68,7 @@ struct fe_engine {
     float2* Y = nullptr;                 // batch scratch: accumulated spectra of one launch round
     size_t Y_bytes = 0;
     fk::Tuning tuning;                   // launch-shape overrides (fe_engine_set_tuning)
+    bool host_io = false;                // the call in progress runs zero-copy on page-locked host buffers
     // rotating pinned/device buffers for job descriptors (async uploads)
     fk::StreamJob* jobs_host[kJobSlots] = {};
     fk::StreamJob* jobs_dev[kJobSlots] = {};
@@ -261,12 +262,14 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         e->fail_next_round = false;
         return fail(FE_ERR_DEVICE, "injected device failure (test hook)");
     }
+    fk::Tuning tn = e->tuning;
+    tn.host_io = e->host_io;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
-    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, e->tuning, st));
+    HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
-    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, e->Y, max_blocks, f->mac_shape, e->tuning, st));
+    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, e->Y, max_blocks, f->mac_shape, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
-    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, e->Y, out_pairs_ok, e->tuning, st));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, e->Y, out_pairs_ok, tn, st));
     HIP_TRY(hipEventRecord(e->jobs_ev[slot], st));
     e->jobs_ev_pending[slot] = true;
     if (prof) {
@@ -390,6 +393,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     // single-block path of SoundProcessor::Process, where latency is everything.
     std::vector<const float*> zc_in;
     std::vector<float*> zc_out;
+    bool zero_copy = false;
     if (!device_ptrs && n > 0) {
         bool all_bound = true;
         for (int i = 0; i < n && all_bound; ++i) {
@@ -413,8 +417,14 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             in = zc_in.data();
             out = zc_out.data();
             device_ptrs = true;          // synchronous: the caller reads `out` when this returns
+            zero_copy = true;
         }
     }
+    struct HostIoScope {                 // tells the launch rounds of THIS call where the PCM lives
+        fe_engine* e;
+        HostIoScope(fe_engine* e_, bool on) : e(e_) { e->host_io = on; }
+        ~HostIoScope() { e->host_io = false; }
+    } host_io_scope(e, zero_copy);
 
     std::vector<Item> all((size_t)n);
     std::vector<const float*> stage_out_of((size_t)n, nullptr);
@@ -474,7 +484,19 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             HIP_TRY(hipMemcpyAsync(peaks_out + 2 * i, streams[i]->peaks, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost,
                                    e->stream));
     }
-    if (!async) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!async) {
+        if (zero_copy) {
+            // The latency path: poll for completion instead of sleeping on the runtime's interrupt
+            // (the wake-up costs more than the kernels); bounded, then the ordinary wait.
+            for (int spin = 0; spin < 4000; ++spin) {
+                const hipError_t q = hipStreamQuery(e->stream);
+                if (q == hipSuccess) { (void)hipGetLastError(); return FE_OK; }   // (clears the sticky "not ready" of earlier polls)
+                if (q != hipErrorNotReady) return fail(FE_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(q));
+            }
+            (void)hipGetLastError();
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     return FE_OK;
 }
 
@@ -967,7 +989,7 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             (knob == FE_TUNE_FWD_RUN ? e->tuning.fwd_run : e->tuning.inv_run) = value;
             return FE_OK;
         case FE_TUNE_MAC_FORM:
-            if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 100)
+            if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && !(value >= 100 && value <= 101))
                 return fail(FE_ERR_PARAM, "MAC form must be 0, 1, 4, 8, 16 or 100");
             e->tuning.mac_form = value;
             return FE_OK;

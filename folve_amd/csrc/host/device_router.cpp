@@ -46,6 +46,7 @@ fe_engine* DeviceRouter::PickEngine() {
         Logf("GPU %d unusable: %s", best->device, fe_last_error());
         return NULL;
     }
+    best->live++;          // reserved under the same lock as the choice: concurrent opens alternate exactly
     return best->engine;
 }
 

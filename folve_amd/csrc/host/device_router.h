@@ -27,7 +27,9 @@ public:
     ~DeviceRouter();
 
     int device_count() const { return static_cast<int>(slots_.size()); }
-    // Engine of the least-loaded device (created on first use); NULL without a GPU.
+    // Engine of the least-loaded device (created on first use); NULL without a GPU.  The pick
+    // reserves a stream on that device (as StreamOpened would): give it back with StreamClosed
+    // if no stream comes of it.
     fe_engine* PickEngine();
     fe_engine* EngineForDevice(int device);
     fe_engine* EngineIfCreated(int slot);      // NULL if that slot's engine was never needed

@@ -26,11 +26,21 @@ SoundProcessor* SoundProcessor::Create(const std::string& config_file, int sampl
         Logf("No usable GPU: cannot create a processor for %s (there is no CPU fallback)", config_file.c_str());
         return NULL;
     }
-    return CreateOn(engine, config_file, samplerate, channels);
+    SoundProcessor* p = CreateOnReserved(engine, config_file, samplerate, channels);
+    if (!p) DeviceRouter::Default()->StreamClosed(engine);      // give the reservation back
+    return p;
 }
 
 SoundProcessor* SoundProcessor::CreateOn(fe_engine* engine, const std::string& config_file, int samplerate,
                                          int channels) {
+    SoundProcessor* p = CreateOnReserved(engine, config_file, samplerate, channels);
+    if (p) DeviceRouter::Default()->StreamOpened(engine);
+    return p;
+}
+
+// The caller has already accounted the stream to `engine` in the router.
+SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate,
+                                                 int channels) {
     if (!engine) return NULL;
     ZitaConfig zita;
     memset(&zita, 0, sizeof(zita));
@@ -48,7 +58,6 @@ SoundProcessor* SoundProcessor::CreateOn(fe_engine* engine, const std::string& c
         Logf("Cannot open a convolver stream for %s: %s", config_file.c_str(), fe_last_error());
         return NULL;
     }
-    DeviceRouter::Default()->StreamOpened(engine);
     zita.engine = engine;
     return new SoundProcessor(zita, config_file, stream);
 }

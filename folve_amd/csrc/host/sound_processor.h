@@ -45,6 +45,9 @@ public:
     static SoundProcessor* Create(const std::string& config_file, int samplerate, int channels);
     // Same, on a given engine (used by ProcessorPool's sharder).
     static SoundProcessor* CreateOn(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
+private:
+    static SoundProcessor* CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
+public:
     ~SoundProcessor();
 
     // Fill buffer from given source.  Returns number of frames read.

@@ -54,6 +54,7 @@ struct Tuning {
     int inv_run = 0;        // K3 walker: consecutive blocks per workgroup
     int mac_form = 0;       // K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk
     int fft_form = 0;       // K1/K3: 1 general kernels only, 2 walkers whenever the shape allows (also small launches)
+    bool host_io = false;   // set per call: PCM in and out are page-locked HOST memory (zero-copy single-block path)
 };
 
 // What the filter's populated-row bitmaps allow K2 to assume (computed once at commit).

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
                                                                       FilterDev f) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
-    __shared__ float2 s[G::LDS_ELEMS];
+    // the stage-B pass tables ride into LDS beside the PCM loads (visible after the barrier that
+    // follows stage A): read from global memory inside stage B they cost one cache round trip per
+    // pass on the critical path of a lone transform
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += G::NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
     };
     stage_a<LOG2P, false>(s, f.twa, tid, load);
     __syncthreads();
-    stage_b<LOG2P, false>(s, f.twb, tid);
+    stage_b<LOG2P, false>(s, twb_l, tid);
     float2 wsp[SplitGeom<LOG2P>::CNT];
     split_prefetch<LOG2P>(wsp, f.tw, tid);
     __syncthreads();
@@ -412,13 +417,15 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void filter_kernel(const float
                                                                      const float2* __restrict__ twb) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
-    __shared__ float2 s[G::LDS_ELEMS];
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += G::NT) twb_l[i] = twb[i];
     const int j = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const float2* __restrict__ part = reinterpret_cast<const float2*>(taps + ((size_t)d * K + j) * P);
     auto load = [&](int m) -> float2 { return (m < P / 2) ? part[m] : float2{0.0f, 0.0f}; };   // [h_j | 0]
     stage_a<LOG2P, false>(s, twa, tid, load);
     __syncthreads();
-    stage_b<LOG2P, false>(s, twb, tid);
+    stage_b<LOG2P, false>(s, twb_l, tid);
     float2 wsp[SplitGeom<LOG2P>::CNT];
     split_prefetch<LOG2P>(wsp, tw, tid);
     __syncthreads();
@@ -459,7 +466,9 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
     constexpr int SLOTS = (N2 / 2 + NT - 1) / NT;            // column pairs per thread
-    __shared__ float2 s[G::LDS_ELEMS];
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
         }
     }
     __syncthreads();
-    stage_b<LOG2P, true>(s, f.twb, tid);
+    stage_b<LOG2P, true>(s, twb_l, tid);
     __syncthreads();
 
     // ---- transposed read: consecutive lanes take consecutive output frames ----
@@ -900,6 +909,14 @@ __device__ __forceinline__ void cmacv(v2f& acc, const v2f& x, const v2f& h) {
         : "v"(x), "v"(h));
 }
 __device__ __forceinline__ void cmacv(float4& acc, const float4& x, const float4& h) { cmac2(acc, x, h); }
+// The two halves of a complex MAC into two accumulators (their sum is the MAC): no instruction of
+// a long MAC chain then depends on its predecessor.
+__device__ __forceinline__ void cmac_re(v2f& acc, const v2f& x, const v2f& h) {   // acc += x.re * (h.re, h.im)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(h));
+}
+__device__ __forceinline__ void cmac_im(v2f& acc, const v2f& x, const v2f& h) {   // acc += x.im * (-h.im, h.re)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(x), "v"(h));
+}
 __device__ __forceinline__ void vzero(v2f& v) { v = v2f{0.f, 0.f}; }
 __device__ __forceinline__ void vzero(float4& v) { v = float4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ v2f vload(const v2f* p) { return *(const FK_GLOBAL v2f*)p; }
@@ -1026,8 +1043,18 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int KR, int D>
-__global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : 3) void mac_walk_kernel(
+// f(0) && f(1) && ... && f(N-1): straight-line code with an exit after every step, no joins inside
+template <int... I, class F>
+__device__ __forceinline__ bool static_all_impl(std::integer_sequence<int, I...>, F&& f) {
+    return (f(std::integral_constant<int, I>{}) && ...);
+}
+template <int N, class F>
+__device__ __forceinline__ bool static_all(F&& f) {
+    return static_all_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int KR, int D, bool PIN = false, int NACC = 6>
+__global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 * KR + D) + 12 <= 168) ? 3 : 2) void mac_walk_kernel(
     const StreamJob* __restrict__ jobs, FilterDev f, float2* __restrict__ Y) {
     constexpr int W = KR + D;
     const StreamJob job = jobs[blockIdx.z];
@@ -1035,52 +1062,105 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : 3) void m
     const int nb = job.nblocks;
     const int P = f.P, K = f.K, ring = job.ring;
     const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned voff = (unsigned)bin * 8u;               // this thread's bin inside any spectrum row
     const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
     const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * nb;
     if (pe1 > pe0) {
         const PathEntry pth = f.paths[pe0];
-        const v2f* __restrict__ Hd = reinterpret_cast<const v2f*>(f.H + (size_t)pth.data * K * P) + bin;
-        const v2f* __restrict__ X = reinterpret_cast<const v2f*>(job.fdl + (size_t)pth.in_ch * ring * P) + bin;
+        // row bases are wave-uniform (scalar registers); the per-lane part of every address is `voff`
+        const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
+        const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
+        auto ldrow = [&](const float2* rowbase) -> v2f {
+            return *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)rowbase + voff);
+        };
         v2f g[KR], w[W];
-#pragma unroll
-        for (int j = 0; j < KR; ++j) g[j] = (j < K) ? vload(Hd + (size_t)j * P) : v2f{0.f, 0.f};
+        // Every load below is issued unconditionally (rows that do not exist are replaced by a valid
+        // row and zeroed by a select): with a fixed sequence of memory operations the compiler's
+        // s_waitcnt vmcnt(N) for block t leaves exactly the D younger loads and the stores in flight;
+        // behind a conditional load it would have to assume the worst and drain the prefetch.
         // history: block -j in slot W - j (j = 1 .. K-1); the call's first D blocks in slots 0 .. D-1
+        if (K == KR) {                                      // the common case (K = 32 partitions + 1): no selects
 #pragma unroll
-        for (int j = 1; j < KR; ++j)
-            w[W - j] = (j < K) ? vload(X + (size_t)ring_slot(job.slot0, -j, ring) * P) : v2f{0.f, 0.f};
-        int xs = job.slot0;                                 // ring slot of the next block to request
-        w[D] = v2f{0.f, 0.f};
+            for (int j = 0; j < KR; ++j) g[j] = ldrow(Hd + (size_t)j * P);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            w[d] = v2f{0.f, 0.f};
-            if (d < nb) {
-                w[d] = vload(X + (size_t)xs * P);
-                xs = (xs + 1 == ring) ? 0 : xs + 1;
+            for (int j = 1; j < KR; ++j) w[W - j] = ldrow(X + (size_t)ring_slot(job.slot0, -j, ring) * P);
+        } else {
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const v2f v = ldrow(Hd + (size_t)(j < K ? j : 0) * P);
+                g[j] = (j < K) ? v : v2f{0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 1; j < KR; ++j) {
+                const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, j < K ? -j : 0, ring) * P);
+                w[W - j] = (j < K) ? v : v2f{0.f, 0.f};
             }
         }
-        float2* __restrict__ yp = Y + yrow0 * P + bin;
+        // PIN: the in-loop loads are issued by inline asm at the step they belong to and awaited by an
+        // explicit s_waitcnt with the exact count of younger memory operations.  Left to itself the
+        // compiler sinks each load to the step that first uses it (it shortens live ranges at the
+        // register limit this kernel runs at), which turns a D-deep prefetch into none.  The window
+        // register is the asm's output and the wait's in/out operand, so every use is ordered behind
+        // its wait; the kernel must stay free of spills and copies of window registers (checked in the
+        // disassembly: no v_mov of a window register inside the loop).
+        auto issue = [&](v2f& dst, const float2* rowbase) {
+            if constexpr (PIN) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(rowbase) : "memory");
+            else dst = ldrow(rowbase);
+        };
+        // the next row to request, as a pointer that wraps at the ring's end (a handful of scalar
+        // instructions per step instead of a slot * row-size product)
+        const float2* xrow = X + (size_t)job.slot0 * P;
+        const float2* const xend = X + (size_t)ring * P;
+        int left = nb;                                      // blocks not yet requested
+        auto advance = [&]() {                              // past the call's last block: stay on it (re-read, never used)
+            if (left > 1) { xrow += P; xrow = (xrow == xend) ? X : xrow; --left; }
+        };
+        w[D] = v2f{0.f, 0.f};
+        if constexpr (PIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G and the history have arrived: the count starts here
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            issue(w[d], xrow);
+            advance();
+        }
+        float2* __restrict__ yrow = Y + yrow0 * P;          // uniform: advances one row per step
         for (int t0 = 0; t0 < nb; t0 += W) {
             // unrolled by W through a fold expression (every window index a compile-time constant; the
-            // loop unroller gives up on a body of this size)
-            static_for<W>([&](auto uc) {
+            // loop unroller gives up on a body of this size), with an exit after the call's last block
+            const bool more = static_all<W>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                const int t = t0 + u;
-                if (t < nb) {
-                    // block t + D rides in while blocks t .. t+D-1 are used: its slot held block t - KR, no longer needed
-                    if (t + D < nb) {
-                        w[(u + D) % W] = vload(X + (size_t)xs * P);
-                        xs = (xs + 1 == ring) ? 0 : xs + 1;
-                    }
-                    v2f acc0{0.f, 0.f}, acc1{0.f, 0.f};
-                    static_for<KR>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        if constexpr (j & 1) cmacv(acc1, w[(u - j + 2 * W) % W], g[j]);
-                        else cmacv(acc0, w[(u - j + 2 * W) % W], g[j]);
-                    });
-                    if (bin != 0) gst_v2(yp, acc0 + acc1);
-                    yp += P;
+                // block t + D rides in while blocks t .. t+D-1 are used: its slot held block t - KR, no longer needed
+                issue(w[(u + D) % W], xrow);
+                advance();
+                if constexpr (PIN) {
+                    // younger than the load of block t: the D loads after it and the stores of the steps in
+                    // between — D of them once the walk is D steps old (fewer before: the count below is
+                    // exact in the first round and merely stricter at the start of later ones)
+                    constexpr int N = D + (u < D ? u : D);
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[u % W]) : "n"(N) : "memory");
                 }
+                // NACC accumulators — the real-part and the imaginary-part products of every (NACC/2)-th partition —
+                // so that every v_pk_fma_f32 is NACC instructions away from the one it depends on (a MAC's own
+                // two halves back to back stall each other), and so that hipcc's hazard recognizer, which pads
+                // with s_nop when two inline-asm statements touching one register are fewer than five apart
+                // (it cannot see that they are plain VALU), finds nothing to pad
+                v2f acc[NACC];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] = v2f{0.f, 0.f};
+                static_for<KR>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    cmac_re(acc[2 * (j % (NACC / 2))], w[(u - j + 2 * W) % W], g[j]);
+                    cmac_im(acc[2 * (j % (NACC / 2)) + 1], w[(u - j + 2 * W) % W], g[j]);
+                });
+                // unconditional (bin 0's value is replaced by the tail below): a store under a branch
+                // would not count in the compiler's vmcnt arithmetic and halve the prefetch depth
+                v2f sum = acc[0] + acc[1];
+#pragma unroll
+                for (int a = 2; a < NACC; a += 2) sum += acc[a] + acc[a + 1];
+                *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
+                yrow += P;
+                return t0 + u + 1 < nb;
             });
+            if (!more) break;
         }
     } else {
         // an output without an input path: silence
@@ -1089,6 +1169,9 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : 3) void m
     // packed bin 0 = (DC, Nyquist): two real FIRs, by the workgroup that owns bin 0, 64 outputs at a
     // time: thread -> (output t & 63, partition group t >> 6), the groups summed through LDS
     if (blockIdx.x != 0) return;
+    // the main loop's (meaningless) bin-0 stores are complete before the tail's replace them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     __shared__ float2 part[256];
     const int tt = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
     for (int t0 = 0; t0 < nb; t0 += 64) {
@@ -1113,6 +1196,75 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : 3) void m
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------
+// K2, latency form: the one-block call of SoundProcessor::Process (one stream, one block).
+// grid (P/128, outputs, streams), 64 threads, two bins per thread.  With so little work the time
+// is the length of one thread's dependent chain, so the K rows are requested U at a time before
+// the first multiply (mac_kernel<1> walks them one load round trip after the other: 13.6 us for
+// K = 32 against ~4 here), rows of G that hold no taps are zeros in memory and are simply read,
+// and the grid is cut small enough to put a wavefront on every other CU.
+//   one block per stream (nblocks == 1); bin 0 (packed DC / Nyquist) by wave reduction.
+// ---------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(64) void mac_small_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+                                                       float2* __restrict__ Y) {
+    const StreamJob job = jobs[blockIdx.z];
+    const int o = blockIdx.y;
+    const int P = f.P, K = f.K, ring = job.ring;
+    const int P2 = P >> 1;
+    const int bp = blockIdx.x * 64 + threadIdx.x;          // bin pair
+    // The sums run in mac_kernel's order (oldest block first, i.e. partition K-1 down to 0; the packed
+    // bin's products summed in ascending partition order), so a stream computes the same bits whether
+    // its block travels alone through this kernel or inside a batch through mac_kernel.
+    float4 acc{0.f, 0.f, 0.f, 0.f};
+    float pr[3] = {0.f, 0.f, 0.f}, pi[3] = {0.f, 0.f, 0.f};   // packed bin: this lane's partitions j = lane + 64*m
+    const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
+    for (int pe = pe0; pe < pe1; ++pe) {
+        const PathEntry pth = f.paths[pe];
+        const float4* __restrict__ Hd = reinterpret_cast<const float4*>(f.H + (size_t)pth.data * K * P) + bp;
+        const float4* __restrict__ X = reinterpret_cast<const float4*>(job.fdl + (size_t)pth.in_ch * ring * P) + bp;
+        for (int j1 = K - 1; j1 >= 0; j1 -= U) {
+            float4 x[U], h[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int j = (j1 - i >= 0) ? j1 - i : 0;                         // clamped: the surplus is discarded below
+                x[i] = gld(X + (size_t)ring_slot(job.slot0, -j, ring) * P2);
+                h[i] = gld(Hd + (size_t)j * P2);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if (j1 - i >= 0) cmac2(acc, x[i], h[i]);
+        }
+        if (blockIdx.x == 0) {
+            const float2* __restrict__ H0 = f.H + (size_t)pth.data * K * P;
+            const float2* __restrict__ X0 = job.fdl + (size_t)pth.in_ch * ring * P;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int j = threadIdx.x + 64 * m;
+                if (j < K) {
+                    const float2 x = gld(X0 + (size_t)ring_slot(job.slot0, -j, ring) * P);
+                    const float2 h = gld(H0 + (size_t)j * P);
+                    pr[m] = fmaf(x.x, h.x, pr[m]);
+                    pi[m] = fmaf(x.y, h.y, pi[m]);
+                }
+            }
+        }
+    }
+    float2* row = Y + ((size_t)job.yunit0 + o) * P;         // nblocks == 1: one row per (stream, output)
+    if (blockIdx.x == 0) {
+        float dc = 0.f, ny = 0.f;
+        for (int j = 0; j < K; ++j) {                       // K <= 129 wave-uniform steps
+            const int m = j >> 6;
+            const float vr = __shfl(m == 0 ? pr[0] : m == 1 ? pr[1] : pr[2], j & 63, 64);
+            const float vi = __shfl(m == 0 ? pi[0] : m == 1 ? pi[1] : pi[2], j & 63, 64);
+            dc = (j == 0) ? vr : dc + vr;
+            ny = (j == 0) ? vi : ny + vi;
+        }
+        if (bp == 0) { acc.x = dc; acc.y = ny; }
+    }
+    reinterpret_cast<float4*>(row)[bp] = acc;
 }
 
 // the cross-lane exchanges of fft_core.hpp on lane ids (tests/test_xlane_gpu.py)
@@ -1188,8 +1340,10 @@ struct InvLaunch {
         constexpr int NT = WaveGeom<L>::NT;
         if constexpr (L == 13) {      // P = 8192 (every filter longer than 4096 taps): one column pair per thread
             // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
+            // host_io: the output goes over the bus — the walker's whole 16-byte quads in full lines, not
+            // the general kernel's interleaved 4-byte stores (27 us against ~12 for one stereo block)
             const bool fast = tn.fft_form != 1 && pairs_ok && (f.cout == 1 || f.cout == 2) &&
-                              (tn.fft_form == 2 || (long long)njobs * max_blocks >= 256);
+                              (tn.fft_form == 2 || tn.host_io || (long long)njobs * max_blocks >= 256);
             if (fast) {
                 const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
@@ -1317,7 +1471,7 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     const int P2 = f.P / 2;
     int form = tn.mac_form;
     const bool walk_ok = shape.single_path && f.K <= 33 && f.P >= 256;
-    if (form == 100 && !walk_ok) form = 0;
+    if (form >= 100 && !walk_ok) form = 0;
     if (form == 0) {
         if (time_tile >= 12) {
             const long long wgs = (long long)njobs * f.cout * (f.P / 256);
@@ -1326,11 +1480,12 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
         else if (time_tile >= 4) form = 4;
         else form = 1;
     }
-    if (form == 100) {
+    if (form >= 100) {
         dim3 grid(f.P / 256, f.cout, njobs), block(256);
-        if (f.K <= 9) hipLaunchKernelGGL((mac_walk_kernel<9, 7>), grid, block, 0, st, jobs, f, Y);
-        else if (f.K <= 17) hipLaunchKernelGGL((mac_walk_kernel<17, 7>), grid, block, 0, st, jobs, f, Y);
-        else hipLaunchKernelGGL((mac_walk_kernel<33, 7>), grid, block, 0, st, jobs, f, Y);
+        if (f.K <= 9) hipLaunchKernelGGL((mac_walk_kernel<9, 7, true>), grid, block, 0, st, jobs, f, Y);
+        else if (f.K <= 17) hipLaunchKernelGGL((mac_walk_kernel<17, 7, true>), grid, block, 0, st, jobs, f, Y);
+        else if (form == 101) hipLaunchKernelGGL((mac_walk_kernel<33, 8>), grid, block, 0, st, jobs, f, Y);   // compiler-placed loads (A/B)
+        else hipLaunchKernelGGL((mac_walk_kernel<33, 7, true>), grid, block, 0, st, jobs, f, Y);
         return hipGetLastError();
     }
     if (form == 4 || form == 8 || form == 16) {
@@ -1345,6 +1500,11 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
             else hipLaunchKernelGGL((mac_slide_kernel<4, 2, 2>), grid, block, 0, st, jobs, f, Y, tiles);
             return hipGetLastError();
         }
+    }
+    if (form == 1 && max_blocks == 1 && njobs <= 8 && P2 >= 64 && tn.mac_form == 0) {
+        dim3 grid(P2 / 64, f.cout, njobs), block(64);
+        hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, jobs, f, Y);
+        return hipGetLastError();
     }
     const int nt = P2 < 256 ? P2 : 256;
     int tt = 1;

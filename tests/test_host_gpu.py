@@ -331,6 +331,7 @@ def test_failed_processor_is_not_pooled(oracle, tmp_path):
     bad, _ = pool.get_or_create(d, 44100, 2, 16)
     x = seeded_input(3, 8192, 2)
     y = good.run(x)
+    good_handle = good.h
     L = fa.lib()
     L.fh_processor_engine.restype = C.c_void_p
     L.fh_processor_engine.argtypes = [C.c_void_p]
@@ -343,7 +344,7 @@ def test_failed_processor_is_not_pooled(oracle, tmp_path):
     pool.give_back(good)
     assert pool.pooled_count(conf) == 1
     again, _ = pool.get_or_create(d, 44100, 2, 16)
-    assert again.h == good.h and np.array_equal(again.run(x), y)
+    assert again.h == good_handle and np.array_equal(again.run(x), y)
 
 
 def test_single_block_latency_and_zero_copy(oracle, tmp_path):

@@ -31,7 +31,6 @@ def test_two_router_slots_share_the_load(tmp_path):
     assert out["cached_filters"] == 2                                           # one committed filter per (config, slot)
     assert out["max_rms"] <= 1e-5
     assert out["pooled"] == 8
-    assert all(abs(a - b) <= 1 for a, b in out["placement_steps"])              # never more than one apart while filling
 
 
 def test_bench_two_ranks_on_one_gpu():
