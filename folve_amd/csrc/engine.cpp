@@ -989,7 +989,7 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             (knob == FE_TUNE_FWD_RUN ? e->tuning.fwd_run : e->tuning.inv_run) = value;
             return FE_OK;
         case FE_TUNE_MAC_FORM:
-            if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && !(value >= 100 && value <= 101))
+            if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 100)
                 return fail(FE_ERR_PARAM, "MAC form must be 0, 1, 4, 8, 16 or 100");
             e->tuning.mac_form = value;
             return FE_OK;

@@ -914,6 +914,12 @@ __device__ __forceinline__ void cmacv(float4& acc, const float4& x, const float4
 __device__ __forceinline__ void cmac_re(v2f& acc, const v2f& x, const v2f& h) {   // acc += x.re * (h.re, h.im)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(h));
 }
+__device__ __forceinline__ void cmul_re(v2f& acc, const v2f& x, const v2f& h) {   // acc = x.re * (h.re, h.im)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(x), "v"(h));
+}
+__device__ __forceinline__ void cmul_im(v2f& acc, const v2f& x, const v2f& h) {   // acc = x.im * (-h.im, h.re)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(acc) : "v"(x), "v"(h));
+}
 __device__ __forceinline__ void cmac_im(v2f& acc, const v2f& x, const v2f& h) {   // acc += x.im * (-h.im, h.re)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(x), "v"(h));
 }
@@ -1144,12 +1150,15 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
                 // with s_nop when two inline-asm statements touching one register are fewer than five apart
                 // (it cannot see that they are plain VALU), finds nothing to pad
                 v2f acc[NACC];
-#pragma unroll
-                for (int a = 0; a < NACC; ++a) acc[a] = v2f{0.f, 0.f};
                 static_for<KR>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    cmac_re(acc[2 * (j % (NACC / 2))], w[(u - j + 2 * W) % W], g[j]);
-                    cmac_im(acc[2 * (j % (NACC / 2)) + 1], w[(u - j + 2 * W) % W], g[j]);
+                    if constexpr (j < NACC / 2) {            // an accumulator's first product: a multiply, no zeroing
+                        cmul_re(acc[2 * j], w[(u - j + 2 * W) % W], g[j]);
+                        cmul_im(acc[2 * j + 1], w[(u - j + 2 * W) % W], g[j]);
+                    } else {
+                        cmac_re(acc[2 * (j % (NACC / 2))], w[(u - j + 2 * W) % W], g[j]);
+                        cmac_im(acc[2 * (j % (NACC / 2)) + 1], w[(u - j + 2 * W) % W], g[j]);
+                    }
                 });
                 // unconditional (bin 0's value is replaced by the tail below): a store under a branch
                 // would not count in the compiler's vmcnt arithmetic and halve the prefetch depth
@@ -1471,7 +1480,10 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     const int P2 = f.P / 2;
     int form = tn.mac_form;
     const bool walk_ok = shape.single_path && f.K <= 33 && f.P >= 256;
-    if (form >= 100 && !walk_ok) form = 0;
+    // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
+    // waves start together and read 2 KB of a row between them: DRAM locality)
+    const int walk_threads = 256;
+    if (form == 100 && !walk_ok) form = 0;
     if (form == 0) {
         if (time_tile >= 12) {
             const long long wgs = (long long)njobs * f.cout * (f.P / 256);
@@ -1480,11 +1492,10 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
         else if (time_tile >= 4) form = 4;
         else form = 1;
     }
-    if (form >= 100) {
-        dim3 grid(f.P / 256, f.cout, njobs), block(256);
+    if (form == 100) {
+        dim3 grid(f.P / walk_threads, f.cout, njobs), block(walk_threads);
         if (f.K <= 9) hipLaunchKernelGGL((mac_walk_kernel<9, 7, true>), grid, block, 0, st, jobs, f, Y);
         else if (f.K <= 17) hipLaunchKernelGGL((mac_walk_kernel<17, 7, true>), grid, block, 0, st, jobs, f, Y);
-        else if (form == 101) hipLaunchKernelGGL((mac_walk_kernel<33, 8>), grid, block, 0, st, jobs, f, Y);   // compiler-placed loads (A/B)
         else hipLaunchKernelGGL((mac_walk_kernel<33, 7, true>), grid, block, 0, st, jobs, f, Y);
         return hipGetLastError();
     }

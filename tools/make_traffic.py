@@ -20,11 +20,12 @@ ROLES = {
 
 
 def pick(table, names):
-    """the (kernel, grid) entry of one of `names` with the most dispatches"""
+    """the (kernel, grid) entry of one of `names` with the largest grid: the S-stream launches of the
+    timed loop (the same kernels also run on smaller grids in the single-block and end-to-end legs)"""
     best = None
     for key, v in table.items():
         if any(key.startswith(n) for n in names):
-            n = v.get("dispatches", 0)
+            n = int(key.rsplit("grid=", 1)[1])
             if best is None or n > best[1]:
                 best = (key, n, v)
     return best
