@@ -1,0 +1,59 @@
+// Microbenchmark: the memory pattern of K2's whole-call walk without its arithmetic.
+// Each thread owns one 8-byte bin and walks T rows: one 8-byte load (D ahead) and one 8-byte store per step.
+// Row-major rows (stride 64 KiB between the rows a thread reads: the engine's layout) against tile-major
+// (a workgroup's 256 bins of consecutive rows are contiguous: stride 2 KiB).  3 workgroups of 256 per CU.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define GL __attribute__((address_space(1)))
+
+template <int D>
+__global__ __launch_bounds__(256) void walk(const v2f* X, v2f* Y, int T, int rows_x, long xstride, long ystride, int tile_major, int spin) {
+    extern __shared__ char lds[];           // occupancy limiter only
+    const int tile = blockIdx.x, unit = blockIdx.y;          // 32 bin tiles, S*C units
+    const long P = 8192;
+    const v2f* x; v2f* y;
+    if (tile_major) { x = X + ((long)unit * 32 + tile) * rows_x * 256 + threadIdx.x; y = Y + ((long)unit * 32 + tile) * T * 256 + threadIdx.x; }
+    else { x = X + (long)unit * rows_x * P + tile * 256 + threadIdx.x; y = Y + (long)unit * T * P + tile * 256 + threadIdx.x; }
+    v2f w[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = *(const GL v2f*)(x + d * xstride);
+    v2f acc{0.f, 0.f};
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int t = t0 + u;
+            v2f v = w[u];
+            const int tn = (t + D < rows_x) ? t + D : rows_x - 1;
+            w[u] = *(const GL v2f*)(x + tn * xstride);
+            for (int k = 0; k < spin; ++k) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(v));
+            acc += v;
+            *(GL v2f*)(y + t * ystride) = acc;
+        }
+    }
+}
+
+int main() {
+    const int S = 128, T = 64, RX = 96;      // 128 (stream, channel) units, 64 outputs, 96-row rings
+    const long P = 8192;
+    v2f *X, *Y;
+    hipMalloc(&X, (size_t)S * RX * P * 8); hipMalloc(&Y, (size_t)S * T * P * 8);
+    hipMemset(X, 0, (size_t)S * RX * P * 8);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int spin : {0, 16, 32, 66}) {
+        for (int tm = 0; tm < 2; ++tm) {
+            const long xs = tm ? 256 : P, ys = tm ? 256 : P;
+            float best = 1e9;
+            for (int rep = 0; rep < 5; ++rep) {
+                hipEventRecord(a);
+                hipLaunchKernelGGL(walk<8>, dim3(32, S), dim3(256), 50 * 1024, 0, X, Y, T, RX, xs, ys, tm, spin);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                if (ms < best) best = ms;
+            }
+            const double bytes = (double)S * P * 8 * (T + 8) + (double)S * P * 8 * T;
+            printf("spin=%2d %s: %.3f ms, %.2f TB/s\n", spin, tm ? "tile-major (2 KiB stride)" : "row-major (64 KiB stride)", best, bytes / best / 1e9);
+        }
+    }
+    return 0;
+}
