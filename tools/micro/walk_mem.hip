@@ -33,6 +33,32 @@ __global__ __launch_bounds__(256) void walk(const v2f* X, v2f* Y, int T, int row
     }
 }
 
+// the same pattern with 16 bytes per lane: 128 threads cover a 256-bin tile
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int D>
+__global__ __launch_bounds__(128) void walk16(const v4f* X, v4f* Y, int T, int rows_x, long xstride, long ystride) {
+    extern __shared__ char lds[];
+    const int tile = blockIdx.x, unit = blockIdx.y;
+    const long P2 = 4096;
+    const v4f* x = X + (long)unit * rows_x * P2 + tile * 128 + threadIdx.x;
+    v4f* y = Y + (long)unit * T * P2 + tile * 128 + threadIdx.x;
+    v4f w[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = *(const GL v4f*)(x + d * xstride);
+    v4f acc{0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int t = t0 + u;
+            v4f v = w[u];
+            const int tn = (t + D < rows_x) ? t + D : rows_x - 1;
+            w[u] = *(const GL v4f*)(x + tn * xstride);
+            acc += v;
+            *(GL v4f*)(y + t * ystride) = acc;
+        }
+    }
+}
+
 int main() {
     const int S = 128, T = 64, RX = 96;      // 128 (stream, channel) units, 64 outputs, 96-row rings
     const long P = 8192;
@@ -54,6 +80,18 @@ int main() {
             const double bytes = (double)S * P * 8 * (T + 8) + (double)S * P * 8 * T;
             printf("spin=%2d %s: %.3f ms, %.2f TB/s\n", spin, tm ? "tile-major (2 KiB stride)" : "row-major (64 KiB stride)", best, bytes / best / 1e9);
         }
+    }
+    for (int wgs : {3, 6}) {
+        float best = 1e9;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(walk16<8>, dim3(32, S), dim3(128), (150 / wgs) * 1024, 0, (const v4f*)X, (v4f*)Y, T, RX, 4096L, 4096L);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) best = ms;
+        }
+        const double bytes = (double)S * P * 8 * (T + 8) + (double)S * P * 8 * T;
+        printf("16 B per lane, %d workgroups of 128 per CU: %.3f ms, %.2f TB/s\n", wgs, best, bytes / best / 1e9);
     }
     return 0;
 }
