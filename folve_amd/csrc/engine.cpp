@@ -832,7 +832,9 @@ int fe_host_alloc(size_t bytes, void** out) {
     if (!out) return fail(FE_ERR_PARAM, "null out");
     *out = nullptr;
     if (bytes == 0) return fail(FE_ERR_PARAM, "zero bytes");
-    hipError_t r = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    // portable + mapped: every GPU of the process can address it (a processor's buffer is allocated
+    // before the router's choice of GPU is visible to the allocator)
+    hipError_t r = hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocMapped);
     if (r != hipSuccess) {
         *out = nullptr;
         return fail(r == hipErrorOutOfMemory ? FE_ERR_ALLOC : FE_ERR_DEVICE, "hipHostMalloc: %s", hipGetErrorString(r));
