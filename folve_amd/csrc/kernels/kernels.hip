@@ -205,7 +205,9 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
     constexpr int P = 1 << LOG2P, N = 2 * P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
     constexpr bool GUARD = (N2 % NT) != 0;
-    __shared__ float2 s[G::LDS_ELEMS];
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;               // stage-B tables ride into LDS beside the PCM loads
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb2[i];
     const StreamJob job = jobs[blockIdx.z];
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
         stage_a_column<LOG2P + 1, false>(s, f.twa2, n2, v[c]);
     }
     __syncthreads();
-    stage_b<LOG2P + 1, false>(s, f.twb2, tid);
+    stage_b<LOG2P + 1, false>(s, twb_l, tid);
     __syncthreads();
     const int slot = ring_slot(job.slot0, b, job.ring);
     float2* __restrict__ rowL = job.fdl + ((size_t)0 * job.ring + slot) * P;
@@ -1334,6 +1336,17 @@ struct FwdLaunch {
                     hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
                     return hipGetLastError();
                 }
+            }
+        }
+        if constexpr (L == 13) {
+            // the one-block call from host memory: ONE 1024-thread workgroup transforms both channels
+            // side by side as a single 2P-point complex FFT and reads the PCM once over the bus (the
+            // per-channel kernel reads it twice and took 18.6 us; this form was the slower one for
+            // large batches — one workgroup per CU — but latency is all that counts here)
+            if (tn.host_io && tn.fft_form != 1 && f.cin == 2 && pairs_ok && f.twa2 && (long long)njobs * max_blocks <= 64) {
+                dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
+                hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
+                return hipGetLastError();
             }
         }
         dim3 grid(max_blocks, f.cin, njobs), block(WaveGeom<L>::NT);
