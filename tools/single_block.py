@@ -12,6 +12,8 @@ import folve_amd as fa
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 size, C = 262144, 2
 eng = fa.Engine(0)
+if os.environ.get("QB_TUNE"):
+    eng.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["QB_TUNE"].split(","))})
 flt = fa.Filter(eng, C, C, size)
 rng = np.random.default_rng(3)
 for c in range(C):
