@@ -172,6 +172,21 @@ def test_benchmarked_shape_parity(engine, oracle):
         assert _rms(second - full[lens[s] + pad:]) <= TOL, s
     # blocks past a ragged tail were never written
     assert float(ys[0][lens[0]:].abs().max()) == 0.0
+    # EVERY stream of the batch, both calls, against an independent float64 FFT convolution (torch.fft on
+    # the GPU: test-only cross-check, never on the product path)
+    n = 2 * T * P + size
+    Hf = [torch.fft.rfft(torch.from_numpy(hd[(c, c)].astype(np.float64)).cuda(), n) for c in range(C)]
+    worst = 0.0
+    for s in range(S):
+        x = torch.zeros(2 * T * P, C, dtype=torch.float64, device="cuda")
+        x[:lens[s]] = xs[s][:lens[s]].double()
+        x[T * P:] = x2[s].double()                       # time advanced by whole blocks: the second call starts at T*P
+        ref = torch.stack([torch.fft.irfft(torch.fft.rfft(x[:, c], n) * Hf[c], n)[:2 * T * P] for c in range(C)], 1)
+        got = torch.cat([ys[s][:lens[s]].double(), y2[s].double()])
+        want = torch.cat([ref[:lens[s]], ref[T * P:]])
+        err = float(torch.sqrt(torch.mean((got - want) ** 2)))
+        worst = max(worst, err / float(torch.sqrt(torch.mean(want ** 2))))
+    assert worst <= TOL, worst
 
 
 def test_injected_failure_leaves_stream_state(tuned, oracle):
