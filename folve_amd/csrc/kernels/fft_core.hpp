@@ -67,19 +67,21 @@ FK_HD float2 conj_csub_i(float2 a, float2 b) {
     return FK_F2(r);
 }
 // a * b
+// Both instructions in ONE asm statement: between two statements where the second reads what the
+// first wrote hipcc's hazard recognizer inserts an s_nop (it cannot see that they are plain VALU).
 FK_HD float2 cmul(float2 a, float2 b) {
     fk_v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(FK_V(a)), "v"(FK_V(b)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
-        : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)), "v"(t));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=v"(r), "=&v"(t) : "v"(FK_V(a)), "v"(FK_V(b)));
     return FK_F2(r);
 }
 // a * conj(b)
 FK_HD float2 cmulc(float2 a, float2 b) {
     fk_v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(FK_V(a)), "v"(FK_V(b)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
-        : "=v"(r) : "v"(FK_V(a)), "v"(FK_V(b)), "v"(t));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r), "=&v"(t) : "v"(FK_V(a)), "v"(FK_V(b)));
     return FK_F2(r);
 }
 // a * (wr + i*wi), wr and wi known at compile time
