@@ -1,5 +1,6 @@
 #!/bin/bash
+# Longer randomized runs than the suite holds (dev aid; GPU): kernel forms, large batches, call patterns.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 900 python tools/soak_forms.py 150 7 2>&1 | tail -8
-timeout 600 python tools/soak_batches.py 60 3 2>&1 | tail -5
-timeout 600 python tools/soak_fuzz.py 1500 2>&1 | tail -5
+timeout 1200 python tools/soak_forms.py ${1:-600} 11 2>&1 | tail -6
+timeout 900 python tools/soak_batches.py ${2:-400} 5 2>&1 | tail -4
+timeout 900 python tools/soak_fuzz.py ${3:-5000} 2>&1 | tail -4
