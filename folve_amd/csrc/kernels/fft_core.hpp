@@ -321,7 +321,7 @@ FK_D void stockham_pass(float2* s, const float2* __restrict__ tw, int tid) {
 // half exchanges of 32 lanes (v_permlane32_swap: lanes 32..63 of the first operand swap with
 // lanes 0..31 of the second) and two of 16 (v_permlane16_swap: the odd rows of the first with
 // the even rows of the second) — the register-file shuffle gfx950 adds for exactly this; no LDS
-// access, no address arithmetic.  tests/test_xlane_gpu.py pins the semantics on the device.
+// access, no address arithmetic.  tests/test_forms_gpu.py (test_xlane_exchange_semantics) pins the semantics on the device.
 FK_D void xlane_swap32(float& a, float& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]);
@@ -347,23 +347,19 @@ FK_D void xlane_transpose4(float& r0, float& r1, float& r2, float& r3) {
 // instead of a round trip through LDS (16 ds_write_b64 + 16 ds_read_b64 per lane saved).
 //   UPPER: write only the upper half of the row (the inverse transform's overlap-save output
 //   keeps the last P of 2P samples = the upper half of every row; the rest is never read).
-template <bool INV, bool UPPER, bool LEAN, class Sync>
+template <bool INV, bool UPPER, class Sync>
 FK_D void fused_pass_16_4(float2* s, const float2* __restrict__ tw16, const float2* __restrict__ tw4, int tid) {
     float2 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = s[phys(tid + r * 64)];
     Sync::sync();
     {
-        // LEAN: only the power-of-two rows are read (4 ds_read_b64 instead of 15) and the other
-        // powers formed as products — 22 more packed multiplies, 22 fewer VGPRs in flight: what lets
-        // the walkers stay at 128 VGPRs (two workgroups per CU)
         float2 w[16];
-        load_twiddles<16, 16, !LEAN>(w, tw16, tid & 15);
+        load_twiddles<16, 16, true>(w, tw16, tid & 15);
 #pragma unroll
         for (int r = 1; r < 16; ++r) v[r] = INV ? cmulc(v[r], w[r]) : cmul(v[r], w[r]);
     }
     dft<16, INV>(v);
-    if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         xlane_transpose4(v[4 * c].x, v[4 * c + 1].x, v[4 * c + 2].x, v[4 * c + 3].x);
@@ -373,7 +369,6 @@ FK_D void fused_pass_16_4(float2* s, const float2* __restrict__ tw16, const floa
     // rotated by W_16^(c*r) — compile-time constants — instead of eight table reads
     float2 wk[4];
     load_twiddles<4, 256, false>(wk, tw4, tid);
-    if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int k = tid + 64 * c;
@@ -390,14 +385,13 @@ FK_D void fused_pass_16_4(float2* s, const float2* __restrict__ tw16, const floa
         dft<4, INV>(u);
 #pragma unroll
         for (int r = UPPER ? 2 : 0; r < 4; ++r) s[phys(k + 256 * r)] = u[r];
-        if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
-    }
+        }
 }
 
 // N-point FFT in place in one padded LDS image by NT threads: natural order in,
 // natural order out.  Ends with the data written and synchronised.
 //   XL: a single wavefront's 1024-point row runs its last two passes fused (fused_pass_16_4).
-template <int LOG2N, int NT, bool INV, class Sync, bool XL = false, bool UPPER = false, bool LEAN = false>
+template <int LOG2N, int NT, bool INV, class Sync, bool XL = false, bool UPPER = false>
 FK_D void lds_fft(float2* s, const float2* __restrict__ ptw, int tid) {
     constexpr int N = 1 << LOG2N;
     constexpr Plan pl = make_plan(LOG2N);
@@ -407,7 +401,7 @@ FK_D void lds_fft(float2* s, const float2* __restrict__ ptw, int tid) {
         static_assert(R0 == 16 && R1 == 16 && R2 == 4 && pl.n == 3, "1024 = 16 * 16 * 4");
         stockham_pass<N, NT, 16, 1, INV, Sync>(s, ptw, tid);
         Sync::sync();
-        fused_pass_16_4<INV, UPPER, LEAN, Sync>(s, ptw + pl.off[1], ptw + pl.off[2], tid);
+        fused_pass_16_4<INV, UPPER, Sync>(s, ptw + pl.off[1], ptw + pl.off[2], tid);
         Sync::sync();
     } else {
         stockham_pass<N, NT, R0, 1, INV, Sync>(s, ptw, tid);
@@ -530,12 +524,11 @@ FK_D void stage_a(float2* s, const float2* __restrict__ twa, int tid, Src&& src)
 // Stage B: every wavefront transforms its own row.
 //   XL: the last two passes of a 1024-point row fused through a cross-lane transpose
 //   UPPER (with XL): only the upper half of every row is written by the last pass
-//   LEAN (with XL): fewest registers (see fused_pass_16_4)
-template <int LOG2P, bool INV, bool XL = true, bool UPPER = false, bool LEAN = false>
+template <int LOG2P, bool INV, bool XL = true, bool UPPER = false>
 FK_D void stage_b(float2* s, const float2* __restrict__ twb, int tid) {
     using G = WaveGeom<LOG2P>;
     float2* row = s + (tid >> 6) * G::RS;
-    lds_fft<G::LOG2N2, 64, INV, WaveSync, XL, UPPER, LEAN>(row, twb, tid & 63);
+    lds_fft<G::LOG2N2, 64, INV, WaveSync, XL, UPPER>(row, twb, tid & 63);
 }
 
 #endif  // __HIPCC__

@@ -14,7 +14,9 @@
 //                per channel; stereo at P = 8192 by a workgroup that walks consecutive blocks (PCM read
 //                once as quads, prefetched), stereo at smaller P as ONE 2P-point complex FFT of
 //                z = L + i*R with the spectra separated by symmetry
-//   K2 mac     : Y(n) = sum_paths sum_{j<=K} Z(n-j) * G(j), time-tiled in registers
+//   K2 mac     : Y(n) = sum_paths sum_{j<=K} Z(n-j) * G(j): per bin a FIR along time — one thread walks a whole
+//                call with the filter row and a window of spectra in registers (every row read once); a
+//                16-output sliding window, a streaming form and a one-block latency form beside it
 //   K3 inverse : Y(n) -> P-point complex IFFT in LDS -> last P samples of the
 //                window, interleaved PCM store, per-stream peak
 //   K0 filter  : taps -> H spectra, 1/(2P) folded in (as zita folds 0.5/parsize), then G
@@ -1278,7 +1280,7 @@ __global__ __launch_bounds__(64) void mac_small_kernel(const StreamJob* __restri
     reinterpret_cast<float4*>(row)[bp] = acc;
 }
 
-// the cross-lane exchanges of fft_core.hpp on lane ids (tests/test_xlane_gpu.py)
+// the cross-lane exchanges of fft_core.hpp on lane ids (tests/test_forms_gpu.py::test_xlane_exchange_semantics)
 __global__ __launch_bounds__(64) void xlane_selftest_kernel(float* __restrict__ out) {
     const int lane = threadIdx.x;
     float a = (float)lane, b = 100.f + (float)lane;
