@@ -6,7 +6,8 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
 2-path 262 144-tap random FIR (P = 8192, K = 32), PCM resident in HBM.  One
 "step" = one batched pass of the hot path (K1 forward FFT -> K2 MAC -> K3
 inverse FFT) over `--blocks` consecutive 8192-frame blocks of every stream
-(run-ahead batches, the BufferThread role in folve).  N > 1 shards independent
+(run-ahead batches, the BufferThread role in folve; default 256 = the >= 256 blocks
+cfg3 gives each stream, i.e. one step is one pass over the whole synthetic input).  N > 1 shards independent
 streams across GPUs (64 per GPU, cfg5 = 512 streams on 8): no data-path
 collective, torch.distributed (RCCL) only for the barrier and the max-over-ranks.
 
@@ -81,7 +82,8 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
-    ap.add_argument("--blocks", type=int, default=64, help="consecutive blocks per stream per step (run-ahead depth)")
+    ap.add_argument("--blocks", type=int, default=256,
+                    help="consecutive blocks per stream per step (run-ahead depth; cfg3 gives every stream >= 256 blocks: one step is the whole of it)")
     ap.add_argument("--taps", type=int, default=262144)
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -132,13 +132,13 @@ def test_mac_forms_agree(tuned, oracle, size, cross):
 
 
 def test_benchmarked_shape_parity(engine, oracle):
-    """bench.py's workload, kernel for kernel: 64 streams x 2 channels x 64 blocks per call through a
-    262 144-tap 2-path filter, streams opened for 64-block calls, device-resident PCM, automatic form
-    choice (walker run length 8, the whole-call MAC walk).  Some ragged tails; a second call carries
+    """bench.py's workload, kernel for kernel: 64 streams x 2 channels x 256 blocks per call through a
+    262 144-tap 2-path filter, streams opened for 256-block calls, device-resident PCM, automatic form
+    choice (walker run length 32, the whole-call MAC walk).  Some ragged tails; a second call carries
     the state.  Checked streams: against the float64 convolution (absolute and relative) and against
-    the oracle."""
+    the oracle; all streams against an independent float64 FFT convolution."""
     torch = pytest.importorskip("torch")
-    S, T, C, size = 64, 64, 2, 262144
+    S, T, C, size = 64, 256, 2, 262144
     rng = np.random.default_rng(3)
     paths = {}
     for c in range(C):
