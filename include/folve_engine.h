@@ -108,7 +108,8 @@ int fe_stream_open(fe_filter *f, int max_blocks_per_call, fe_stream **out);
  * becomes), and its binding to a stream: host-pointer calls on that stream whose in/out lie inside
  * the bound range are read and written by the kernels directly over the bus — no staging copies.
  * The binding is a promise that the range stays allocated until it is unbound (buf = NULL) or the
- * stream is closed.  In-place calls (in == out) are fine. */
+ * stream is closed.  In-place calls (in == out) are fine for one block (what SoundProcessor::Process
+ * does, sound-processor.cc:62-63,98-127) and for any length when ninp == nout. */
 int fe_host_alloc(size_t bytes, void **out);
 void fe_host_free(void *p);
 int fe_stream_bind_host_buffer(fe_stream *s, void *buf, size_t bytes);
