@@ -149,3 +149,30 @@ def test_sstring_restatement_vs_reference_build(oracle, size):
         assert n == n_ref, (src, size, n, n_ref)
         if n_ref:
             assert val == buf.value, (src, size)
+
+
+def test_committed_traffic_table_is_consistent():
+    """profiles/traffic.json (what bench.py's roofline reads): every shape entry names its profile, carries bytes
+    and kernel-trace times for all three kernels, and pairs them with a launch of the right kernel family."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    family = {"forward": ("forward_",), "mac": ("mac_",), "inverse": ("inverse_",)}
+    shapes = [k for k in tj if k != "_comment"]
+    assert "S64_T256_K32_C2" in shapes                          # bench.py's default shape
+    for key in shapes:
+        e = tj[key]
+        assert e["profile"] and os.path.exists(os.path.join(root, "profiles", e["profile"] + "_summary.json")), key
+        blocks = int(key.split("_")[1][1:])
+        for role, prefixes in family.items():
+            assert e["bytes"][role] > 0 and e["avg_ns"][role] > 0, (key, role)
+            assert e["kernels"][role].startswith(prefixes), (key, role, e["kernels"][role])
+            assert e["read"][role] + e["write"][role] == e["bytes"][role]
+        if blocks > 1:                                           # run-ahead launches: the fast forms
+            assert e["kernels"]["forward"].startswith("forward_walker_kernel")
+            assert e["kernels"]["mac"].startswith(("mac_walk_kernel", "mac_slide_kernel"))
+            assert e["kernels"]["inverse"].startswith("inverse_walker_kernel")
+            # bytes / time: a physically possible HBM rate
+            for role in family:
+                assert e["bytes"][role] / e["avg_ns"][role] < 8000.0, (key, role)      # GB/s

@@ -19,16 +19,16 @@ ROLES = {
 }
 
 
-def pick(table, names):
-    """the (kernel, grid) entry of one of `names` with the largest grid: the S-stream launches of the
-    timed loop (the same kernels also run on smaller grids in the single-block and end-to-end legs)"""
-    best = None
-    for key, v in table.items():
-        if any(key.startswith(n) for n in names):
-            n = int(key.rsplit("grid=", 1)[1])
-            if best is None or n > best[1]:
-                best = (key, n, v)
-    return best
+def pick_key(names):
+    """The (kernel, grid) launch that stands for a role: of the first kernel in `names` that was launched at
+    all, the grid on which it spent the most time — the S-stream launches of the timed and profiled loops
+    (the same kernels also run on other grids in the single-block and end-to-end legs)."""
+    trace = summ.get("kernel_trace", {})
+    for n in names:
+        cands = [(v["dispatches"] * v["avg_ns"], k) for k, v in trace.items() if k.startswith(n)]
+        if cands:
+            return max(cands)[1]
+    return None
 
 
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -44,15 +44,18 @@ tj["_comment"] = ("HBM bytes per launch from rocprofv3 PMC passes over `python b
 for mode, blocks in (("T", T), ("1", 1)):
     entry = {"profile": tag, "bytes": {}, "avg_ns": {}, "read": {}, "write": {}, "kernels": {}}
     for role, names in ROLES[mode].items():
-        h = pick(summ.get("hbm_per_dispatch", {}), names)
-        t = pick(summ.get("kernel_trace", {}), names)
+        key = pick_key(names)
+        if key is None:
+            continue
+        h = summ.get("hbm_per_dispatch", {}).get(key)
+        t = summ.get("kernel_trace", {}).get(key)
         if h:
-            entry["bytes"][role] = int(h[2]["hbm_bytes"])
-            entry["read"][role] = int(h[2]["hbm_read_bytes_corrected"])
-            entry["write"][role] = int(h[2]["hbm_write_bytes"])
-            entry["kernels"][role] = h[0]
+            entry["bytes"][role] = int(h["hbm_bytes"])
+            entry["read"][role] = int(h["hbm_read_bytes_corrected"])
+            entry["write"][role] = int(h["hbm_write_bytes"])
+            entry["kernels"][role] = key
         if t:
-            entry["avg_ns"][role] = round(t[2]["avg_ns"], 1)
+            entry["avg_ns"][role] = round(t["avg_ns"], 1)
     if entry["bytes"]:
         tj["S%d_T%d_K%d_C%d" % (S, blocks, K, C)] = entry
 json.dump(tj, open(tpath, "w"), indent=1)
