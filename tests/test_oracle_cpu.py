@@ -168,7 +168,7 @@ def test_committed_traffic_table_is_consistent():
         for role, prefixes in family.items():
             assert e["bytes"][role] > 0 and e["avg_ns"][role] > 0, (key, role)
             assert e["kernels"][role].startswith(prefixes), (key, role, e["kernels"][role])
-            assert e["read"][role] + e["write"][role] == e["bytes"][role]
+            assert abs(e["read"][role] + e["write"][role] - e["bytes"][role]) <= 2          # (each rounded to an integer)
         if blocks > 1:                                           # run-ahead launches: the fast forms
             assert e["kernels"]["forward"].startswith("forward_walker_kernel")
             assert e["kernels"]["mac"].startswith(("mac_walk_kernel", "mac_slide_kernel"))
