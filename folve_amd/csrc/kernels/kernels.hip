@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     float4 q[COLS][HR];
     auto request_whole = [&](int c, const float* __restrict__ base) {
 #pragma unroll
-        for (int h = 0; h < HR; ++h) q[c][h] = gld_u4(base + (size_t)(h * N2 + c * NT) * 4, (unsigned)tid * 16u);
+        for (int h = 0; h < HR; ++h) q[c][h] = gld_u4_once(base + (size_t)(h * N2 + c * NT) * 4, (unsigned)tid * 16u);
     };
     auto request_partial = [&](int b) {                       // a stream's short last block
         const long long f0 = (long long)b * P;
@@ -642,11 +642,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     float2 ya[N1], yb[N1];
     auto request_a = [&](const float2* __restrict__ y) {
 #pragma unroll
-        for (int n1 = 0; n1 < N1; ++n1) ya[n1] = gld_u2(y + n1 * N2, (unsigned)ca * 8u);
+        for (int n1 = 0; n1 < N1; ++n1) ya[n1] = gld_u2_once(y + n1 * N2, (unsigned)ca * 8u);
     };
     auto request_b = [&](const float2* __restrict__ y) {
 #pragma unroll
-        for (int n1 = 0; n1 < N1; ++n1) yb[n1] = gld_u2(y + n1 * N2, (unsigned)cb * 8u);
+        for (int n1 = 0; n1 < N1; ++n1) yb[n1] = gld_u2_once(y + n1 * N2, (unsigned)cb * 8u);
     };
     request_a(row_of(b0, 0));
     request_b(row_of(b0, 0));
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
                     if constexpr (COUT == 2) {
                         const float2 l = zl[c];
                         if constexpr (WHOLE) {
-                            gst_u4(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
+                            gst_u4_once(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
                             pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
                             pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
                         } else {

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Dev aid: build folve_amd/variants/libfolve_amd_<name>.so with extra -D flags on the kernels
+# (host objects are reused from the product build).  usage: tools/build_variant.sh name -DFOO -DBAR
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+make -s -C folve_amd/csrc >/dev/null
+mkdir -p folve_amd/variants /tmp/fkv_$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC "$@" -c folve_amd/csrc/kernels/kernels.hip -o /tmp/fkv_$name/kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o folve_amd/variants/libfolve_amd_$name.so /tmp/fkv_$name/kernels.o \
+    $(find folve_amd/csrc/build -name '*.o' ! -name kernels.o) -lpthread
+echo built folve_amd/variants/libfolve_amd_$name.so
