@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
 // slots beyond the K rows still needed receive the loads of blocks t+1 .. t+D while they are in
 // flight — the window IS the prefetch buffer.  The t loop is unrolled by W, so every slot index
 // (u - j) mod W is static: no register moves, no indexing.
-//   one path per output (the launcher checks), K <= KR, bin 0 (packed DC / Nyquist) by the tail.
+//   one path per output (the launcher checks), K <= KR; bin 0 (packed DC / Nyquist: two real spectra) falls out of
+//   the same instructions, the re-part and im-part accumulators being kept apart until the store.
 // ---------------------------------------------------------------------------
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
@@ -1073,6 +1074,7 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
     const int P = f.P, K = f.K, ring = job.ring;
     const int bin = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned voff = (unsigned)bin * 8u;               // this thread's bin inside any spectrum row
+    const bool packed = bin == 0;
     const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
     const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * nb;
     if (pe1 > pe0) {
@@ -1164,11 +1166,16 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
                         cmac_im(acc[2 * (j % (NACC / 2)) + 1], w[(u - j + 2 * W) % W], g[j]);
                     }
                 });
-                // unconditional (bin 0's value is replaced by the tail below): a store under a branch
-                // would not count in the compiler's vmcnt arithmetic and halve the prefetch depth
-                v2f sum = acc[0] + acc[1];
+                // the re-part and the im-part accumulators are summed apart: the packed bin 0 holds (DC, Nyquist),
+                // two REAL spectra, whose products are (sum x.re g.re, sum x.im g.im) = (re-part.lo, -im-part.lo)
+                v2f sre = acc[0], sim = acc[1];
 #pragma unroll
-                for (int a = 2; a < NACC; a += 2) sum += acc[a] + acc[a + 1];
+                for (int a = 2; a < NACC; a += 2) { sre += acc[a]; sim += acc[a + 1]; }
+                v2f sum = sre + sim;
+                sum.x = packed ? sre.x : sum.x;
+                sum.y = packed ? -sim.x : sum.y;
+                // unconditional: a store under a branch would not count in the compiler's vmcnt arithmetic
+                // and halve the prefetch depth
                 *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
                 yrow += P;
                 return t0 + u + 1 < nb;
@@ -1178,36 +1185,6 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
     } else {
         // an output without an input path: silence
         for (int t = 0; t < nb; ++t) gst_v2(Y + (yrow0 + t) * P + bin, v2f{0.f, 0.f});
-    }
-    // packed bin 0 = (DC, Nyquist): two real FIRs, by the workgroup that owns bin 0, 64 outputs at a
-    // time: thread -> (output t & 63, partition group t >> 6), the groups summed through LDS
-    if (blockIdx.x != 0) return;
-    // the main loop's (meaningless) bin-0 stores are complete before the tail's replace them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ float2 part[256];
-    const int tt = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
-    for (int t0 = 0; t0 < nb; t0 += 64) {
-        float re = 0.f, im = 0.f;
-        if (pe1 > pe0 && t0 + tt < nb) {
-            const PathEntry pth = f.paths[pe0];
-            const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
-            const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
-            for (int j = grp; j < K; j += ngrp) {
-                const float2 x = gld(X + (size_t)ring_slot(job.slot0, t0 + tt - j, ring) * P);
-                const float2 h = gld(Hd + (size_t)j * P);
-                re = fmaf(x.x, h.x, re);
-                im = fmaf(x.y, h.y, im);
-            }
-        }
-        part[threadIdx.x] = float2{re, im};
-        __syncthreads();
-        if (threadIdx.x < 64 && t0 + tt < nb) {
-            float2 sum = part[tt];
-            for (int k = 1; k < ngrp; ++k) { sum.x += part[tt + 64 * k].x; sum.y += part[tt + 64 * k].y; }
-            gst(Y + (yrow0 + t0 + tt) * P, sum);
-        }
-        __syncthreads();
     }
 }
 

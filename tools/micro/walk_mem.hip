@@ -4,6 +4,7 @@
 // (a workgroup's 256 bins of consecutive rows are contiguous: stride 2 KiB).  3 workgroups of 256 per CU.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define GL __attribute__((address_space(1)))
 
@@ -13,8 +14,11 @@ __global__ __launch_bounds__(256) void walk(const v2f* X, v2f* Y, int T, int row
     const int tile = blockIdx.x, unit = blockIdx.y;          // 32 bin tiles, S*C units
     const long P = 8192;
     const v2f* x; v2f* y;
-    if (tile_major) { x = X + ((long)unit * 32 + tile) * rows_x * 256 + threadIdx.x; y = Y + ((long)unit * 32 + tile) * T * 256 + threadIdx.x; }
-    else { x = X + (long)unit * rows_x * P + tile * 256 + threadIdx.x; y = Y + (long)unit * T * P + tile * 256 + threadIdx.x; }
+    // tile_major: bit 0 = X, bit 1 = Y
+    if (tile_major & 1) x = X + ((long)unit * 32 + tile) * rows_x * 256 + threadIdx.x;
+    else x = X + (long)unit * rows_x * P + tile * 256 + threadIdx.x;
+    if (tile_major & 2) y = Y + ((long)unit * 32 + tile) * T * 256 + threadIdx.x;
+    else y = Y + (long)unit * T * P + tile * 256 + threadIdx.x;
     v2f w[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) w[d] = *(const GL v2f*)(x + d * xstride);
@@ -59,16 +63,35 @@ __global__ __launch_bounds__(128) void walk16(const v4f* X, v4f* Y, int T, int r
     }
 }
 
-int main() {
-    const int S = 128, T = 64, RX = 96;      // 128 (stream, channel) units, 64 outputs, 96-row rings
+// reference: plain 16-byte grid-stride copy of the same number of bytes
+__global__ __launch_bounds__(256) void copy16(const v4f* a, v4f* b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+
+int main(int argc, char** argv) {
+    // 128 (stream, channel) units; T outputs, RX-row rings (default: 64 outputs, 96 rows; "256 288" = the 256-block call,
+    // whose 4.6 GB per launch no cache holds from one launch to the next)
+    const int S = 128, T = argc > 1 ? atoi(argv[1]) : 64, RX = argc > 2 ? atoi(argv[2]) : 96;
     const long P = 8192;
     v2f *X, *Y;
     hipMalloc(&X, (size_t)S * RX * P * 8); hipMalloc(&Y, (size_t)S * T * P * 8);
     hipMemset(X, 0, (size_t)S * RX * P * 8);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int spin : {0, 16, 32, 66}) {
-        for (int tm = 0; tm < 2; ++tm) {
-            const long xs = tm ? 256 : P, ys = tm ? 256 : P;
+    {
+        const size_t n = (size_t)S * T * P * 8 / 16;
+        float best = 1e9;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(copy16, dim3(256 * 8), dim3(256), 0, 0, (const v4f*)X, (v4f*)Y, n);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) best = ms;
+        }
+        printf("copy16 of %.0f MB: %.3f ms, %.2f TB/s (read + write)\n", n * 16 / 1e6, best, 2.0 * n * 16 / best / 1e9);
+    }
+    for (int spin : {0, 16}) {
+        for (int tm = 0; tm < 4; ++tm) {
+            const long xs = (tm & 1) ? 256 : P, ys = (tm & 2) ? 256 : P;
             float best = 1e9;
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(a);
@@ -78,7 +101,7 @@ int main() {
                 if (ms < best) best = ms;
             }
             const double bytes = (double)S * P * 8 * (T + 8) + (double)S * P * 8 * T;
-            printf("spin=%2d %s: %.3f ms, %.2f TB/s\n", spin, tm ? "tile-major (2 KiB stride)" : "row-major (64 KiB stride)", best, bytes / best / 1e9);
+            printf("spin=%2d %s: %.3f ms, %.2f TB/s\n", spin, tm == 0 ? "X rows, Y rows (64 KiB stride)" : tm == 1 ? "X tiles (2 KiB stride), Y rows" : tm == 2 ? "X rows, Y tiles" : "X tiles, Y tiles", best, bytes / best / 1e9);
         }
     }
     for (int wgs : {3, 6}) {
