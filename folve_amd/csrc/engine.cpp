@@ -264,6 +264,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     }
     fk::Tuning tn = e->tuning;
     tn.host_io = e->host_io;
+    tn.one_job = (nj == 1 && dj == e->jobs_host[slot]) ? e->jobs_host[slot] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));

@@ -34,13 +34,13 @@
 namespace fk {
 
 #ifdef FOLVE_PHASE_TRACE
-// TRACE build only (make TRACE=1): cycles per phase, summed over workgroups by thread 0.
+// TRACE build only (make TRACE=1): time per phase in 10 ns ticks (s_memrealtime), summed over workgroups by thread 0.
 __device__ unsigned long long g_phase[2][8];
-#define PH_INIT() unsigned long long ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH_INIT() unsigned long long ph_t = wall_clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PH(i)                                                     \
     do {                                                          \
         __builtin_amdgcn_sched_barrier(0);                        \
-        const unsigned long long ph_n = clock64();                \
+        const unsigned long long ph_n = wall_clock64();              \
         ph_acc[i] += ph_n - ph_t;                                 \
         ph_t = ph_n;                                              \
         __builtin_amdgcn_sched_barrier(0);                        \
@@ -50,10 +50,20 @@ __device__ unsigned long long g_phase[2][8];
         if (threadIdx.x == 0)                                     \
             for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase[kid][ph_i], ph_acc[ph_i]); \
     } while (0)
+// time stamps (10 ns ticks, id in the top byte) of workgroup 0's thread 0, appended to a ring: the
+// timeline of the one-block call as the GPU sees it (tools/phase_trace_single.py)
+__device__ unsigned long long g_stamp[256];
+__device__ unsigned int g_stamp_n;
+#define STAMP(id)                                                                                     \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)               \
+            g_stamp[atomicAdd(&g_stamp_n, 1u) & 255u] = ((unsigned long long)(id) << 56) | (wall_clock64() & 0xffffffffffffffull); \
+    } while (0)
 #else
 #define PH_INIT() do {} while (0)
 #define PH(i) do {} while (0)
 #define PH_FLUSH(kid) do {} while (0)
+#define STAMP(id) do {} while (0)
 #endif
 
 namespace {
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
     constexpr bool GUARD = (N2 % NT) != 0;
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;               // stage-B tables ride into LDS beside the PCM loads
+    STAMP(1);
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb2[i];
     const StreamJob job = jobs[blockIdx.z];
     const int b = blockIdx.x;
@@ -257,6 +268,89 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
             gst(rowR + k, float2{0.5f * (a.y + bb.y), -0.5f * (a.x - bb.x)});
         }
     }
+    STAMP(2);
+}
+
+// ---------------------------------------------------------------------------
+// K1, latency form (P = 8192, stereo): the one-block call of SoundProcessor::Process.
+// grid (blocks, 1, streams), 1024 threads = two halves of 512; half h transforms channel h in its own
+// LDS image, both at once (the walker's workgroup does them one after the other: 14.7 us in the kernel
+// for a lone stereo block; the one 2P-point transform of forward_dual_kernel 12.8 us).  Both halves
+// request the block's (L0, R0, L1, R1) quads and keep their channel's two samples (fetching every quad
+// once and sorting through LDS measured the same: the 64 KB take ~4.5 us over the bus either way).
+// ---------------------------------------------------------------------------
+template <int LOG2P, bool XL>
+__global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void forward_pair_kernel(const StreamJob* __restrict__ jobs,
+                                                                               StreamJob one, FilterDev f) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
+    static_assert(N1 == 8 && COLS == 2 && NT == 512, "pair form needs P = 8192");
+    constexpr int HR = N1 / 2;
+    __shared__ float2 s2[2][G::LDS_ELEMS + G::TWB];
+    const int half = threadIdx.x / NT, tid = threadIdx.x - half * NT;   // half is wave-uniform
+    float2* const s = s2[half];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    STAMP(1);
+    const StreamJob job = jobs ? jobs[blockIdx.z] : one;      // one: the descriptor by value (Tuning::one_job)
+    const int b = blockIdx.x;
+    if (b >= job.nblocks) return;
+    const float* __restrict__ in = job.in;
+    const long long f0 = (long long)b * P;
+    float2 x[COLS][HR];
+    if (f0 + P <= job.nframes) {
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) {
+                const float4 q = gld_u4_once(in + (size_t)f0 * 2 + (size_t)(h * N2 + c * NT) * 4, (unsigned)tid * 16u);
+                x[c][h] = half ? float2{q.y, q.w} : float2{q.x, q.z};
+            }
+    } else {                                                  // a stream's short last block
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) {
+                const long long fr = f0 + 2 * (h * N2 + tid + c * NT);
+                float2 v{0.f, 0.f};
+                if (fr < job.nframes) v.x = gld(in + fr * 2 + half);
+                if (fr + 1 < job.nframes) v.y = gld(in + fr * 2 + 2 + half);
+                x[c][h] = v;
+            }
+    }
+    STAMP(10);                                                // descriptor read, PCM requested
+    for (int i = tid; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    const float2 a1 = f.twa[0 * N2 + tid], a2 = f.twa[1 * N2 + tid], a4 = f.twa[2 * N2 + tid];
+    const float2 w0 = f.tw[tid];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        float2 z[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) z[n1] = (n1 < HR) ? x[c][n1 < HR ? n1 : 0] : float2{0.0f, 0.0f};
+        StageATw<LOG2P> tw;
+        if (c == 0) {
+            tw.w[0] = a1; tw.w[1] = a2; tw.w[2] = a4;
+        } else {                                              // column tid + 512: W^(512*k1) = e^(-i*pi*k1/8)
+            tw.w[0] = cmul_const(a1, kCos16[1], -kSin16[1]);
+            tw.w[1] = cmul_const(a2, kCos16[2], -kSin16[2]);
+            tw.w[2] = float2{a4.y, -a4.x};
+        }
+        tw.w[3] = float2{1.f, 0.f};
+        stage_a_column<LOG2P, false>(s, tw, tid + c * NT, z);
+    }
+    STAMP(11);                                                // PCM arrived, stage A
+    __syncthreads();
+    STAMP(12);
+    stage_b<LOG2P, false, XL>(s, twb_l, tid);
+    STAMP(13);
+    __syncthreads();
+    STAMP(14);
+    float2 wsp[SplitGeom<LOG2P>::CNT];                        // bins tid + 512*c: e^(-i*pi*512*c/P) = e^(-i*pi*c/16)
+#pragma unroll
+    for (int c = 0; c < SplitGeom<LOG2P>::CNT; ++c) wsp[c] = c ? cmul_const(w0, kCos32[c], -kSin32[c]) : w0;
+    const int slot = ring_slot(job.slot0, b, job.ring);
+    split_and_store<LOG2P>(s, wsp, tid, job.fdl + ((size_t)half * job.ring + slot) * P, 1.0f);
+    STAMP(2);
 }
 
 // ---------------------------------------------------------------------------
@@ -284,8 +378,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     constexpr int HR = N1 / 2;                                // rows of a column that hold PCM (the rest is the zero padding)
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
+    PH_INIT();
+    STAMP(1);
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     __syncthreads();
+    PH(6);                                                    // tables into LDS
     const StreamJob job = jobs[blockIdx.z];
     const int b0 = blockIdx.x * run;
     if (b0 >= job.nblocks) return;
@@ -320,7 +417,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
             }
     };
     const int bw = (int)min((long long)b1, max((long long)b0, job.nframes / P));   // blocks [b0, bw) are whole
-    PH_INIT();
+    PH(7);                                                    // job descriptor
     if (b0 < bw) { request_whole(0, in + (size_t)b0 * P * 2); request_whole(1, in + (size_t)b0 * P * 2); }
     else request_partial(b0);
 
@@ -408,6 +505,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
         do_block(std::false_type{}, bw, nullptr, tid);
     }
     PH_FLUSH(0);
+    STAMP(2);
 }
 
 // ---------------------------------------------------------------------------
@@ -618,6 +716,8 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     // for the prefetch and the previous block's stores.
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
+    PH_INIT();
+    STAMP(5);
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     __syncthreads();
     const StreamJob job = jobs[blockIdx.z];
@@ -652,7 +752,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     request_b(row_of(b0, 0));
     float* __restrict__ out = job.out;
     float pk_s = 0.0f, pk_a = 0.0f;
-    PH_INIT();
+    PH(7);                                                    // tables into LDS, job descriptor, first Y row requested
 
     // One block, all of its channels.  WHOLE: every frame of the block exists — true for all
     // blocks but a stream's last.  The loop over whole blocks issues a FIXED number of loads and
@@ -776,12 +876,127 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     for (int b = b0; b < bw; ++b) do_block(std::true_type{}, b);
     if (bw < b1) do_block(std::false_type{}, bw);             // a stream's short last block
     PH_FLUSH(1);
+    STAMP(6);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         pk_s = fmaxf(pk_s, __shfl_xor(pk_s, off, 64));
         pk_a = fmaxf(pk_a, __shfl_xor(pk_a, off, 64));
     }
     if ((tid & 63) == 0) {
+        atomicMax(job.peaks + 0, __float_as_uint(pk_s));
+        atomicMax(job.peaks + 1, __float_as_uint(pk_a));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3, latency form (P = 8192, stereo): the one-block call of SoundProcessor::Process.
+// grid (blocks, 1, streams), 1024 threads = two halves of 512; half h folds and transforms output h in
+// its own LDS image, both at once (the walker's workgroup: one after the other, 11.4 us in the kernel
+// for a lone stereo block).  When both images stand, every thread reads the L samples from one and the
+// R samples from the other and stores whole (L0, R0, L1, R1) quads — half h the even / odd ones.
+// ---------------------------------------------------------------------------
+template <int LOG2P, bool XL>
+__global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void inverse_pair_kernel(const StreamJob* __restrict__ jobs,
+                                                                               StreamJob one, FilterDev f,
+                                                                               const float2* __restrict__ Y) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
+    static_assert(N1 == 8 && NT == N2 / 2, "pair form needs P = 8192 (one column pair per thread)");
+    constexpr int OUTS = (P / 2) / NT;                        // output complex samples per thread and channel (8)
+    __shared__ float2 s2[2][G::LDS_ELEMS + G::TWB];
+    const int half = threadIdx.x / NT, t = threadIdx.x - half * NT;     // half is wave-uniform
+    float2* const s = s2[half];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    STAMP(5);
+    const StreamJob job = jobs ? jobs[blockIdx.z] : one;
+    const int b = blockIdx.x;
+    if (b >= job.nblocks) return;
+    const int ca = t, cb = (t == 0) ? N2 / 2 : N2 - t;
+    const float2* __restrict__ y = Y + ((size_t)job.yunit0 + (size_t)half * job.nblocks + b) * P;
+    float2 ya[N1], yb[N1];
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) ya[n1] = gld_u2_once(y + n1 * N2, (unsigned)ca * 8u);
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) yb[n1] = gld_u2_once(y + n1 * N2, (unsigned)cb * 8u);
+    for (int i = t; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    const float2 wb = f.tw[ca];                               // e^(-i*pi*k/P) at k = ca; k = n1*N2 + ca is a rotation by e^(-i*pi*n1/8)
+    StageATw<LOG2P> atw_a = load_stage_a_tw<LOG2P>(f.twa, ca);
+    StageATw<LOG2P> atw_b = load_stage_a_tw<LOG2P>(f.twa, cb);
+    atw_a.w[3] = atw_b.w[3] = float2{1.f, 0.f};
+    // ---- Hermitian fold in registers (see inverse_kernel / inverse_walker_kernel) ----
+    float2 za[N1], zb[N1];
+    if (t != 0) {
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const float2 a = ya[n1], bb = yb[N1 - 1 - n1];
+            const float2 e = cadd_conj(a, bb);
+            const float2 dd = csub_conj(a, bb);
+            const float2 wa = n1 ? cmul_const(wb, kCos16[n1], -kSin16[n1]) : wb;
+            const float2 oo = cmulc(dd, wa);
+            za[n1] = cadd_i(e, oo);
+            zb[N1 - 1 - n1] = conj_csub_i(e, oo);
+        }
+    } else {
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            if (n1 == 0) {
+                const float2 y0 = ya[0];
+                za[0] = float2{y0.x + y0.y, y0.x - y0.y};
+            } else {
+                const float2 a = ya[n1], bb = ya[N1 - n1];
+                const float2 e = cadd_conj(a, bb);
+                const float2 dd = csub_conj(a, bb);
+                const float2 oo = cmul_const(dd, kCos16[n1], kSin16[n1]);   // thread 0: k = n1*N2, conj(e^(-i*pi*n1/8))
+                za[n1] = cadd_i(e, oo);
+            }
+            const float2 a = yb[n1], bb = yb[N1 - 1 - n1];
+            const float2 e = cadd_conj(a, bb);
+            const float2 dd = csub_conj(a, bb);
+            const float2 oo = cmul_const(dd, kMidCos8[n1], kMidSin8[n1]);
+            zb[n1] = cadd_i(e, oo);
+        }
+    }
+    stage_a_column<LOG2P, true>(s, atw_a, t, za);
+    stage_a_column<LOG2P, true>(s, atw_b, cb, zb);
+    __syncthreads();
+    stage_b<LOG2P, true, XL, XL>(s, twb_l, t);                // XL: only the upper half of every row (the kept samples) is written
+    __syncthreads();
+    // ---- both images stand: quads c = half, half + 2, .. of this thread's frames ----
+    float* __restrict__ out = job.out;
+    const long long fb = (long long)b * P;
+    const bool whole = fb + P <= job.nframes;
+    float pk_s = 0.0f, pk_a = 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < OUTS / 2; ++cc) {
+        const int c = 2 * cc + half;
+        const int q = P / 2 + t + c * NT;                     // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
+        const float2 l = s2[0][G::at(q)], r = s2[1][G::at(q)];
+        const long long fr = fb + 2 * q - P;
+        if (whole) {
+            gst_u4_once(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, r.x, l.y, r.y});
+            pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(r.x, r.y)));
+            pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(r.x), fabsf(r.y))));
+        } else {
+            if (fr < job.nframes) {
+                gst(out + fr * 2, l.x); gst(out + fr * 2 + 1, r.x);
+                pk_s = fmaxf(pk_s, fmaxf(l.x, r.x));
+                pk_a = fmaxf(pk_a, fmaxf(fabsf(l.x), fabsf(r.x)));
+            }
+            if (fr + 1 < job.nframes) {
+                gst(out + fr * 2 + 2, l.y); gst(out + fr * 2 + 3, r.y);
+                pk_s = fmaxf(pk_s, fmaxf(l.y, r.y));
+                pk_a = fmaxf(pk_a, fmaxf(fabsf(l.y), fabsf(r.y)));
+            }
+        }
+    }
+    STAMP(6);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pk_s = fmaxf(pk_s, __shfl_xor(pk_s, off, 64));
+        pk_a = fmaxf(pk_a, __shfl_xor(pk_a, off, 64));
+    }
+    if ((t & 63) == 0) {
         atomicMax(job.peaks + 0, __float_as_uint(pk_s));
         atomicMax(job.peaks + 1, __float_as_uint(pk_a));
     }
@@ -1198,9 +1413,10 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
 //   one block per stream (nblocks == 1); bin 0 (packed DC / Nyquist) by wave reduction.
 // ---------------------------------------------------------------------------
 template <int U>
-__global__ __launch_bounds__(64) void mac_small_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+__global__ __launch_bounds__(64) void mac_small_kernel(const StreamJob* __restrict__ jobs, StreamJob one, FilterDev f,
                                                        float2* __restrict__ Y) {
-    const StreamJob job = jobs[blockIdx.z];
+    STAMP(3);
+    const StreamJob job = jobs ? jobs[blockIdx.z] : one;   // one: the descriptor by value (Tuning::one_job)
     const int o = blockIdx.y;
     const int P = f.P, K = f.K, ring = job.ring;
     const int P2 = P >> 1;
@@ -1255,6 +1471,7 @@ __global__ __launch_bounds__(64) void mac_small_kernel(const StreamJob* __restri
         if (bp == 0) { acc.x = dc; acc.y = ny; }
     }
     reinterpret_cast<float4*>(row)[bp] = acc;
+    STAMP(4);
 }
 
 // the cross-lane exchanges of fft_core.hpp on lane ids (tests/test_forms_gpu.py::test_xlane_exchange_semantics)
@@ -1318,13 +1535,12 @@ struct FwdLaunch {
             }
         }
         if constexpr (L == 13) {
-            // the one-block call from host memory: ONE 1024-thread workgroup transforms both channels
-            // side by side as a single 2P-point complex FFT and reads the PCM once over the bus (the
-            // per-channel kernel reads it twice and took 18.6 us; this form was the slower one for
-            // large batches — one workgroup per CU — but latency is all that counts here)
-            if (tn.host_io && tn.fft_form != 1 && f.cin == 2 && pairs_ok && f.twa2 && (long long)njobs * max_blocks <= 64) {
-                dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
-                hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
+            // the one-block call from host memory: ONE 1024-thread workgroup, a half per channel, both
+            // transforms at once (one workgroup per CU: latency is all that counts here)
+            if (tn.host_io && tn.fft_form == 0 && f.cin == 2 && pairs_ok && (long long)njobs * max_blocks <= 64) {
+                dim3 grid(max_blocks, 1, njobs), block(2 * WaveGeom<L>::NT);
+                if (tn.one_job) hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f);
+                else hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, jobs, StreamJob{}, f);
                 return hipGetLastError();
             }
         }
@@ -1343,6 +1559,13 @@ struct InvLaunch {
             // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
             // host_io: the output goes over the bus — the walker's whole 16-byte quads in full lines, not
             // the general kernel's interleaved 4-byte stores (27 us against ~12 for one stereo block)
+            // the one-block call from host memory, stereo: both outputs at once in one 1024-thread workgroup
+            if (tn.host_io && tn.fft_form == 0 && pairs_ok && f.cout == 2 && (long long)njobs * max_blocks <= 64) {
+                dim3 grid(max_blocks, 1, njobs), block(2 * NT);
+                if (tn.one_job) hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f, Y);
+                else hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, jobs, StreamJob{}, f, Y);
+                return hipGetLastError();
+            }
             const bool fast = tn.fft_form != 1 && pairs_ok && (f.cout == 1 || f.cout == 2) &&
                               (tn.fft_form == 2 || tn.host_io || (long long)njobs * max_blocks >= 256);
             if (fast) {
@@ -1506,7 +1729,8 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     }
     if (form == 1 && max_blocks == 1 && njobs <= 8 && P2 >= 64 && tn.mac_form == 0) {
         dim3 grid(P2 / 64, f.cout, njobs), block(64);
-        hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, jobs, f, Y);
+        if (tn.one_job) hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f, Y);
+        else hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, jobs, StreamJob{}, f, Y);
         return hipGetLastError();
     }
     const int nt = P2 < 256 ? P2 : 256;
@@ -1527,7 +1751,13 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
 }  // namespace fk
 
 #ifdef FOLVE_PHASE_TRACE
-// kernel 0 = forward_dual, 1 = inverse_walker; out[16]; reset != 0 clears the counters afterwards
+// the stamp ring (256 entries) and the number of stamps written so far
+extern "C" int fe_debug_stamps(unsigned long long* out256, unsigned int* count) {
+    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(fk::g_stamp), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(fk::g_stamp_n), sizeof(unsigned int)) != hipSuccess) return -1;
+    return 0;
+}
+// kernel 0 = forward_walker, 1 = inverse_walker; out[16]; reset != 0 clears the counters afterwards
 extern "C" int fe_debug_phases(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fk::g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     if (reset) {

@@ -131,6 +131,56 @@ def test_mac_forms_agree(tuned, oracle, size, cross):
             assert _rms(y2[s] - full[lens[s] + pad:]) <= TOL, (form, s)
 
 
+def test_one_block_call_forms_agree(tuned, oracle):
+    """The drop-in call (one synchronous block on a page-locked buffer bound to the stream, SoundProcessor::Process,
+    /root/reference/sound-processor.cc:98-127) through its three K1/K3 forms: the 1024-thread pair kernels it uses
+    by itself, the walkers (fft_form = 2) and the general kernels (fft_form = 1) — whole blocks, then a short last
+    block, then a reset and a replay."""
+    import ctypes
+    L = fa.lib()
+    size, C = 100000, 2
+    rng = np.random.default_rng(77)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+    sp, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+    P = flt.block_size
+    assert P == 8192
+    valid = [P, P, P, P, P - 1234]
+    x = rng.uniform(-1, 1, (sum(valid), C)).astype(np.float32)
+    buf = ctypes.c_void_p()
+    assert L.fe_host_alloc(P * C * 4, ctypes.byref(buf)) == 0
+    arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_float)), shape=(P, C))
+    outs, peaks = {}, {}
+    try:
+        for form in (0, 2, 1):
+            tuned.set_tuning(fft_form=form)
+            st = flt.open_stream(1)
+            assert L.fe_stream_bind_host_buffer(st.h, buf, P * C * 4) == 0
+            for rep in range(2):
+                got, pos = [], 0
+                for v in valid:
+                    arr[:] = 0
+                    arr[:v] = x[pos:pos + v]
+                    ps, pa = ctypes.c_float(), ctypes.c_float()
+                    assert L.fe_stream_process(st.h, buf, v, buf, ctypes.byref(ps), ctypes.byref(pa)) == 0
+                    got.append(arr[:v].copy())
+                    pos += v
+                y = np.concatenate(got)
+                if rep == 0:
+                    outs[form], peaks[form] = y, (ps.value, pa.value)
+                    st.reset()
+                else:
+                    assert np.array_equal(y, outs[form]), form      # replay after reset: the same bits
+            st.close()
+    finally:
+        L.fe_host_free(buf)
+    y64 = oracle.linear_convolution_f64(x, dense_taps(paths, size), C)
+    for form in (0, 2, 1):
+        assert _rms(outs[form] - y64) <= TOL and _rms(outs[form] - y64) / _rms(y64) <= TOL, form
+        assert _rms(outs[form] - outs[1]) <= 2e-6, form
+        assert abs(peaks[form][0] - max(0.0, float(outs[form].max()))) <= 1e-6, form
+        assert abs(peaks[form][1] - float(np.abs(outs[form]).max())) <= 1e-6, form
+
+
 def test_benchmarked_shape_parity(engine, oracle):
     """bench.py's workload, kernel for kernel: 64 streams x 2 channels x 256 blocks per call through a
     262 144-tap 2-path filter, streams opened for 256-block calls, device-resident PCM, automatic form
