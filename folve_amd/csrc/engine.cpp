@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <time.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -381,11 +382,26 @@ int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* c
     return FE_OK;
 }
 
+#ifdef FOLVE_PHASE_TRACE
+// TRACE build only: where the host's share of the one-block call goes (ns, summed; tools/phase_trace_single.py)
+static unsigned long long g_host_ns[8];     // [0] entry -> launches enqueued, [1] -> completion seen, [2] calls, [3] polls, [4] exit -> next entry
+static unsigned long long g_host_last_exit;
+static unsigned long long host_now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec;
+}
+#define HOST_T(var) const unsigned long long var = host_now_ns()
+#else
+#define HOST_T(var) do {} while (0)
+#endif
+
 // peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
                    const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr) {
     bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
     const bool async = device_ptrs && (flags & FE_ASYNC);
+    HOST_T(t_entry);
     HIP_TRY(hipSetDevice(e->device));
 
     // Host-pointer calls whose every buffer lies in page-locked memory bound to its stream run
@@ -487,10 +503,19 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     }
     if (!async) {
         if (zero_copy) {
+            HOST_T(t_launched);
             // The latency path: poll for completion instead of sleeping on the runtime's interrupt
             // (the wake-up costs more than the kernels); bounded, then the ordinary wait.
             for (int spin = 0; spin < 4000; ++spin) {
                 const hipError_t q = hipStreamQuery(e->stream);
+#ifdef FOLVE_PHASE_TRACE
+                if (q == hipSuccess) {
+                    const unsigned long long t_done = host_now_ns();
+                    g_host_ns[0] += t_launched - t_entry; g_host_ns[1] += t_done - t_launched; g_host_ns[2] += 1; g_host_ns[3] += spin + 1;
+                    if (g_host_last_exit) g_host_ns[4] += t_entry - g_host_last_exit;
+                    g_host_last_exit = t_done;
+                }
+#endif
                 if (q == hipSuccess) { (void)hipGetLastError(); return FE_OK; }   // (clears the sticky "not ready" of earlier polls)
                 if (q != hipErrorNotReady) return fail(FE_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(q));
             }
@@ -507,6 +532,14 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
 // C ABI
 // ===========================================================================
 extern "C" {
+
+#ifdef FOLVE_PHASE_TRACE
+int fe_debug_host_times(unsigned long long* out8, int reset) {
+    for (int i = 0; i < 8; ++i) out8[i] = g_host_ns[i];
+    if (reset) { for (int i = 0; i < 8; ++i) g_host_ns[i] = 0; g_host_last_exit = 0; }
+    return 0;
+}
+#endif
 
 const char* fe_last_error(void) { return g_last_error.c_str(); }
 

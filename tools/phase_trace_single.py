@@ -31,12 +31,19 @@ for _ in range(40):
     L.fe_stream_process(st.h, buf, P, buf, None, None)
 ph = (ctypes.c_ulonglong * 16)()
 assert L.fe_debug_phases(ph, 1) == 0
+hostt = (ctypes.c_ulonglong * 8)()
+L.fe_debug_host_times.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+L.fe_debug_host_times(hostt, 1)
 t0 = time.perf_counter()
 for _ in range(n):
     L.fe_stream_process(st.h, buf, P, buf, None, None)
 dt = (time.perf_counter() - t0) / n
 assert L.fe_debug_phases(ph, 1) == 0
 print("%.1f us per block (instrumented build)" % (dt * 1e6))
+L.fe_debug_host_times(hostt, 1)
+nc = max(1, hostt[2])
+print("host: entry -> three launches enqueued %.2f us | -> completion seen %.2f us (%.1f polls) | return -> next entry (caller's loop) %.2f us"
+      % (hostt[0] / nc / 1e3, hostt[1] / nc / 1e3, hostt[3] / nc, hostt[4] / max(1, nc - 1) / 1e3))
 names = [
     ("forward_walker", ["PCM wait + stage A", "barrier", "stage B", "barrier", "split + stores", "barrier", "prologue: tables -> LDS", "prologue: job descriptor"]),
     ("inverse_walker", ["Y wait + fold", "prefetch + stage A", "barrier", "stage B", "barrier", "read + stores", "barrier", "prologue"]),
