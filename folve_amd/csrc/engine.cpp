@@ -163,7 +163,7 @@ int get_twiddles(fe_engine* e, int log2P, fk::FftTables* out) {
     out->tw = it->second;
     out->twa = it->second + off.o[0];
     out->twb = it->second + off.o[1];
-    const bool has2 = off.o[2] < off.total;           // the 2P-point (stereo) geometry exists for P >= 512
+    const bool has2 = off.o[2] < off.total;           // the 2P-point (stereo) geometry exists for 512 <= P <= 4096
     out->twa2 = has2 ? it->second + off.o[2] : nullptr;
     out->twb2 = has2 ? it->second + off.o[3] : nullptr;
     return FE_OK;

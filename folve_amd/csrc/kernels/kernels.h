@@ -43,7 +43,7 @@ struct FilterDev {
     const float2* tw;       // exp(-2*pi*i*k/(2P)), k in [0, 2P)   (real-FFT split / fold)
     const float2* twa;      // stage A rows k1 = 1,2,4: exp(-2*pi*i*n2*k1/P)  (fft_core.hpp WaveGeom)
     const float2* twb;      // stage B (per-wavefront N2-point FFT) pass tables
-    const float2* twa2;     // the same two for the 2P-point transform of the stereo kernels (NULL if P < 512)
+    const float2* twa2;     // the same two for the 2P-point transform of the stereo kernels (NULL if P < 512 or P = 8192)
     const float2* twb2;
 };
 

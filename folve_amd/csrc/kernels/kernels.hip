@@ -1628,7 +1628,7 @@ struct TableLayout {
         n[2] = WaveGeom<L>::TWB;
         n[5] = WaveGeom<L>::N2;
         n[6] = WaveGeom<L>::LOG2N2;
-        if constexpr (L >= 9) {
+        if constexpr (L >= 9 && L < 13) {                  // P = 8192 has its own stereo forms (walker, pair)
             n[3] = WaveGeom<L + 1>::TWA;
             n[4] = WaveGeom<L + 1>::TWB;
             n[7] = WaveGeom<L + 1>::N2;
