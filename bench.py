@@ -20,6 +20,10 @@ contract's keys:
                  HIP-event time / 8 TB/s: always <= 1.  The streaming formula of SURVEY.md §8(d)
                  does not describe a time-tiled kernel (it re-uses rows on chip); it is printed as
                  `frac_alg` with "applicable": false, and applies in `roofline_streaming`
+                 `roofline.measured_hbm`: this GPU's read / write / copy rates measured in this run by plain
+                 streaming kernels (fe_engine_hbm_rates), and every kernel's time against its own PMC bytes
+                 at those rates — what "speed of light" is for a kernel that writes
+  steady_state — 400 more steps of the same launches, with socket power and shader clock (amdgpu hwmon)
   roofline_streaming — one block per call (SoundProcessor::Process granularity): K2 streams K rows
                  per block, algorithmic and moved bytes coincide
   end_to_end   — the same batch from page-locked HOST buffers, PCIe inside the timed region
@@ -356,6 +360,26 @@ def main():
                                 for k in kms},
                 "path": {"min_bytes_per_block_channel": int(tb["total"]),
                          "frac_of_min_bytes": round(tb["total"] * units_per_launch * world * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4)}}
+
+    # What this GPU's HBM gives ANY kernel, reads and writes apart (fe_engine_hbm_rates: plain 16-byte streaming
+    # kernels over 2 GiB, HIP events), and each kernel's time against its own bytes at those two rates one after
+    # the other.  The nominal 8 TB/s of `peak` is out of reach of a kernel that writes.
+    try:
+        rates = eng.hbm_rates(1 << 31, 20)
+        rd, wr = (entry.get("read") or {}), (entry.get("write") or {})
+        model = {}
+        for k in kms:
+            if traffic is not None and rd.get(k) and wr.get(k):
+                t_model = rd[k] / (rates["read"] * 1e9) + wr[k] / (rates["write"] * 1e9)
+                model[k] = {"model_ms": round(t_model * 1e3, 4), "frac": round(t_model / (kms[k] * 1e-3), 4)}
+        roofline["measured_hbm"] = {"read_GBs": round(rates["read"], 1), "write_GBs": round(rates["write"], 1),
+                                    "copy_GBs": round(rates["copy"], 1),
+                                    "what": "plain streaming kernels on this GPU in this run: 16 bytes per lane over 2 GiB, "
+                                            "20 passes, HIP events (copy counts bytes read + written)",
+                                    "kernel_time_at_these_rates": model or None,
+                                    "frac_meaning": "(PMC read bytes / read rate + PMC write bytes / write rate) / measured kernel time"}
+    except Exception as ex:                                  # a measurement aid: never fails the bench line
+        roofline["measured_hbm"] = {"error": str(ex)}
 
     extras = world == 1 and not args.no_extras
     # ---- streaming form (one block per stream per call = SoundProcessor::Process granularity): here K2

@@ -78,6 +78,7 @@ ENGINE_SYMBOLS = [
     ("fe_engine_set_profiling", _i, [_vp, _i]),
     ("fe_engine_get_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
     ("fe_engine_reset_profile", _i, [_vp]),
+    ("fe_engine_hbm_rates", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
 ]
 
 
@@ -163,6 +164,12 @@ class Engine:
         ms = (C.c_double * FE_K_COUNT)()
         _chk(lib().fe_engine_get_profile(self.h, n, ms), "fe_engine_get_profile")
         return {KERNEL_NAMES[k]: {"launches": int(n[k]), "ms": float(ms[k])} for k in range(FE_K_COUNT)}
+
+    def hbm_rates(self, nbytes=1 << 31, reps=20):
+        """GB/s this GPU's HBM gives plain streaming kernels: {"read", "write", "copy"} (copy counts both ways)."""
+        g = (C.c_double * 3)()
+        _chk(lib().fe_engine_hbm_rates(self.h, nbytes, reps, g), "fe_engine_hbm_rates")
+        return {"read": float(g[0]), "write": float(g[1]), "copy": float(g[2])}
 
     def close(self):
         if self.h:

@@ -1071,6 +1071,36 @@ int fe_engine_get_profile(fe_engine* e, long long launches[FE_K_COUNT], double m
     return FE_OK;
 }
 
+int fe_engine_hbm_rates(fe_engine* e, size_t bytes, int reps, double gbs[3]) {
+    if (!e || !gbs || reps < 1 || bytes < ((size_t)1 << 20)) return fail(FE_ERR_PARAM, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    bytes &= ~(size_t)15;
+    DevTmp a, b;
+    if (hipMalloc(&a.p, bytes) != hipSuccess || hipMalloc(&b.p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FE_ERR_ALLOC, "device allocation of 2 x %zu bytes failed", bytes);
+    }
+    HIP_TRY(hipMemsetAsync(a.p, 0x3c, bytes, e->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    hipError_t rc = hipEventCreate(&e1);
+    for (int mode = 0; mode < 3 && rc == hipSuccess; ++mode) {
+        for (int w = 0; w < 2 && rc == hipSuccess; ++w) rc = fk::launch_hbm_probe(mode, a.p, b.p, bytes, e->stream);
+        if (rc == hipSuccess) rc = hipEventRecord(e0, e->stream);
+        for (int r = 0; r < reps && rc == hipSuccess; ++r) rc = fk::launch_hbm_probe(mode, a.p, b.p, bytes, e->stream);
+        if (rc == hipSuccess) rc = hipEventRecord(e1, e->stream);
+        if (rc == hipSuccess) rc = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, e0, e1);
+        if (rc == hipSuccess) gbs[mode] = (mode == 2 ? 2.0 : 1.0) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    }
+    (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (rc != hipSuccess) return fail(FE_ERR_DEVICE, "HBM probe: %s", hipGetErrorString(rc));
+    return FE_OK;
+}
+
 int fe_engine_reset_profile(fe_engine* e) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);

@@ -81,6 +81,9 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
 // xlane_swap32 on (lane, 100 + lane) first operand, out[64..127] second operand, out[128..255]
 // the same for xlane_swap16, out[256..511] the four registers after xlane_transpose4 of (10*i + lane/16).
 hipError_t launch_xlane_selftest(float* out512, hipStream_t st);
+// Measurement hook (bench.py): plain streaming kernels over `bytes` of `a` (and `b`), 16 bytes per lane —
+// mode 0 read a, 1 write b, 2 copy a -> b.  What this GPU's HBM delivers to ANY kernel, read and written apart.
+hipError_t launch_hbm_probe(int mode, const void* a, void* b, size_t bytes, hipStream_t st);
 struct FftTables { const float2* tw; const float2* twa; const float2* twb; const float2* twa2; const float2* twb2; };
 // K0: time-domain taps [ndata][K*P] -> Htmp [ndata][K][P] (scaled by 1/(2P)) -> G [ndata][K+1][P].
 hipError_t launch_filter_transform(const float* taps, float2* Htmp, float2* Gs, int ndata, int K, int log2P,

@@ -1607,6 +1607,29 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
     return dispatch_log2p<InvLaunch>(f.log2P, jobs, njobs, max_blocks, f, Y, walker_ok, tn, st);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void hbm_read_kernel(const v4f* __restrict__ a, v4f* __restrict__ sink, size_t n) {
+    v4f acc{0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += a[i];
+    if (acc.x == 12345.678f) sink[0] = acc;                   // never true for the probe's data: keeps the loads
+}
+__global__ __launch_bounds__(256) void hbm_write_kernel(v4f* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = v4f{1.f, 2.f, 3.f, 4.f};
+}
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const v4f* __restrict__ a, v4f* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+}  // namespace
+
+hipError_t launch_hbm_probe(int mode, const void* a, void* b, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 16;
+    dim3 grid(2048), block(256);                              // 8 workgroups per CU, grid-stride
+    if (mode == 0) hipLaunchKernelGGL(hbm_read_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);
+    else if (mode == 1) hipLaunchKernelGGL(hbm_write_kernel, grid, block, 0, st, (v4f*)b, n);
+    else hipLaunchKernelGGL(hbm_copy_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_xlane_selftest(float* out512, hipStream_t st) {
     hipLaunchKernelGGL(xlane_selftest_kernel, dim3(1), dim3(64), 0, st, out512);
     return hipGetLastError();

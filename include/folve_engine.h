@@ -164,6 +164,10 @@ int fe_engine_set_profiling(fe_engine *e, int on);
 /* accumulated since the last reset: launches and milliseconds per kernel */
 int fe_engine_get_profile(fe_engine *e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]);
 int fe_engine_reset_profile(fe_engine *e);
+/* What this GPU's HBM delivers to plain streaming kernels (16 bytes per lane, `bytes` per pass, `reps`
+ * passes, HIP events): gbs[0] reading, gbs[1] writing, gbs[2] copying (bytes read + written), in GB/s.
+ * bench.py prints them beside the nominal 8 TB/s its roofline fraction divides by. */
+int fe_engine_hbm_rates(fe_engine *e, size_t bytes, int reps, double gbs[3]);
 
 #ifdef __cplusplus
 }
