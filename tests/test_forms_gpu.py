@@ -181,6 +181,15 @@ def test_one_block_call_forms_agree(tuned, oracle):
         assert abs(peaks[form][1] - float(np.abs(outs[form]).max())) <= 1e-6, form
 
 
+def test_hbm_rate_hook(engine):
+    """bench.py's measurement hook: three finite, ordered-of-magnitude rates (HBM3E: TB/s, not GB/s)."""
+    r = engine.hbm_rates(256 << 20, 5)
+    assert set(r) == {"read", "write", "copy"}
+    assert all(500.0 < v < 20000.0 for v in r.values()), r
+    with pytest.raises(Exception):
+        engine.hbm_rates(1024, 1)                          # below the 1 MiB floor: FE_ERR_PARAM
+
+
 def test_benchmarked_shape_parity(engine, oracle):
     """bench.py's workload, kernel for kernel: 64 streams x 2 channels x 256 blocks per call through a
     262 144-tap 2-path filter, streams opened for 256-block calls, device-resident PCM, automatic form
