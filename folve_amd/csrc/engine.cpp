@@ -247,12 +247,13 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         e->jobs_cap[slot] = cap;
     }
     memcpy(e->jobs_host[slot], jobs.data(), bytes);
-    // Small launches (the single-block path) read their descriptors straight from the page-locked
-    // buffer — no upload command in front of K1; large ones upload them once (thousands of
-    // workgroups should not each fetch a descriptor over the bus).
+    // Small launches (the single-block path, and the combined one-block calls of many file threads, whose
+    // PCM crosses the bus anyway) read their descriptors straight from the page-locked buffer — no upload
+    // command in front of K1 (10 - 15 us of copy-engine latency per round); large ones upload them once
+    // (thousands of workgroups should not each fetch a descriptor over the bus).
     const fk::StreamJob* dj = e->jobs_dev[slot];
     const int nj = (int)jobs.size();
-    if ((long long)nj * max_blocks <= 16) {
+    if ((long long)nj * max_blocks <= (e->host_io ? 256 : 16)) {
         dj = e->jobs_host[slot];
     } else {
         HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
