@@ -72,6 +72,8 @@ ENGINE_SYMBOLS = [
     ("fe_stream_reset_peaks", _i, [_vp]),
     ("fe_stream_blocks_done", _ll, [_vp]),
     ("fe_batch_process", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _i]),
+    ("fe_batch_submit", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _pvp]),
+    ("fe_ticket_wait", _i, [_vp]),
     ("fe_batch_get_peaks", _i, [_pvp, _i, C.POINTER(_f), C.POINTER(_f)]),
     ("fe_engine_set_tuning", _i, [_vp, _i, _i]),
     ("fe_debug_xlane", _i, [_vp, _vp]),

@@ -87,12 +87,18 @@ struct fe_engine {
     // (PCIe is full duplex; a serial H2D - compute - D2H uses one direction at a time).
     hipStream_t cp_in = nullptr, cp_out = nullptr;
     hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ticket_events;   // idle completion events of fe_batch_submit tickets
     // profiling
     bool fail_next_round = false;        // test hook: the next launch round fails with FE_ERR_DEVICE
     bool profiling = false;
     hipEvent_t pev[4] = {};
     long long prof_launches[FE_K_COUNT] = {};
     double prof_ms[FE_K_COUNT] = {};
+};
+
+struct fe_ticket {                  // a submitted batch whose outputs are not yet known to be in the caller's buffers
+    fe_engine* e = nullptr;          // (holds a reference)
+    hipEvent_t ev = nullptr;
 };
 
 struct PathHost {
@@ -399,7 +405,8 @@ static unsigned long long host_now_ns() {
 
 // peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
-                   const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr) {
+                   const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr,
+                   hipEvent_t submit_event = nullptr) {
     bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
     const bool async = device_ptrs && (flags & FE_ASYNC);
     HOST_T(t_entry);
@@ -438,6 +445,8 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             zero_copy = true;
         }
     }
+    if (submit_event && !zero_copy)
+        return fail(FE_ERR_UNSUPPORTED, "fe_batch_submit needs every buffer inside page-locked memory bound to its stream");
     struct HostIoScope {                 // tells the launch rounds of THIS call where the PCM lives
         fe_engine* e;
         HostIoScope(fe_engine* e_, bool on) : e(e_) { e->host_io = on; }
@@ -501,6 +510,10 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         for (int i = 0; i < n; ++i)
             HIP_TRY(hipMemcpyAsync(peaks_out + 2 * i, streams[i]->peaks, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost,
                                    e->stream));
+    }
+    if (submit_event) {                  // fe_batch_submit: the caller waits on the ticket, not here
+        HIP_TRY(hipEventRecord(submit_event, e->stream));
+        return FE_OK;
     }
     if (!async) {
         if (zero_copy) {
@@ -610,6 +623,7 @@ static void engine_release(fe_engine* e) {
         if (e->jobs_ev[i]) (void)hipEventDestroy(e->jobs_ev[i]);
     }
     for (int i = 0; i < 4; ++i) if (e->pev[i]) (void)hipEventDestroy(e->pev[i]);
+    for (hipEvent_t ev : e->ticket_events) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -983,6 +997,63 @@ int fe_batch_process(fe_stream* const* streams, int n, const float* const* in, c
     fe_engine* e = streams[0]->eng;
     std::lock_guard<std::mutex> lk(e->mu);
     return process_locked(e, streams, n, in, nframes, out, flags);
+}
+
+int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, const long long* nframes,
+                    float* const* out, fe_ticket** ticket) {
+    if (!ticket) return fail(FE_ERR_PARAM, "null ticket");
+    *ticket = nullptr;
+    if (n < 1 || !streams || !in || !nframes || !out) return fail(FE_ERR_PARAM, "bad batch arguments");
+    if (!streams[0]) return fail(FE_ERR_PARAM, "null stream");
+    fe_engine* e = streams[0]->eng;
+    fe_ticket* t = new (std::nothrow) fe_ticket();
+    if (!t) return fail(FE_ERR_ALLOC, "out of memory");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->ticket_events.empty()) {
+        t->ev = e->ticket_events.back();
+        e->ticket_events.pop_back();
+    } else if (hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        delete t;
+        return fail(FE_ERR_DEVICE, "hipEventCreate failed");
+    }
+    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev);
+    if (rc) {
+        e->ticket_events.push_back(t->ev);
+        delete t;
+        return rc;
+    }
+    t->e = e;
+    e->refs.fetch_add(1);
+    *ticket = t;
+    return FE_OK;
+}
+
+int fe_ticket_wait(fe_ticket* t) {
+    if (!t) return fail(FE_ERR_PARAM, "null ticket");
+    fe_engine* e = t->e;
+    int rc = FE_OK;
+    if (hipSetDevice(e->device) != hipSuccess) rc = fail(FE_ERR_DEVICE, "hipSetDevice failed");
+    // the latency path: poll (bounded), then the runtime's wait — as fe_stream_process does
+    bool done = false;
+    for (int spin = 0; rc == FE_OK && !done && spin < 4000; ++spin) {
+        const hipError_t q = hipEventQuery(t->ev);
+        if (q == hipSuccess) done = true;
+        else if (q != hipErrorNotReady) rc = fail(FE_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(q));
+    }
+    (void)hipGetLastError();             // (clears the sticky "not ready" of the polls)
+    if (rc == FE_OK && !done) {
+        const hipError_t w = hipEventSynchronize(t->ev);
+        if (w != hipSuccess) rc = fail(FE_ERR_DEVICE, "hipEventSynchronize: %s", hipGetErrorString(w));
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->ticket_events.push_back(t->ev);
+    }
+    delete t;
+    engine_release(e);
+    return rc;
 }
 
 int fe_stream_process_blocks(fe_stream* s, const float* in, long long nframes, float* out) {

@@ -48,35 +48,103 @@ void BatchScheduler::ReleaseEngine(fe_engine* engine) {
 }
 
 int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error) {
-    Request r{s, in, valid_frames, out, 0, false, std::string()};
+    Request r{s, in, valid_frames, out, 0, std::string(), kParked, nullptr, 0};
     std::unique_lock<std::mutex> lk(mu_);
-    queue_.push_back(&r);
     stats_.requests++;
-    while (!r.done) {
-        if (busy_) {                       // a call is in flight: park until its thread has looked at the queue
-            finished_.wait(lk);
-            continue;
-        }
-        // The GPU is idle: this thread takes everything that is parked (its own block included).
+    if (!busy_) {
+        // The GPU is idle: this block runs at once, by itself (nothing can be parked while the GPU is idle).
         busy_ = true;
-        const size_t cap = static_cast<size_t>(g_max_batch.load());
-        const size_t n = queue_.size() < cap ? queue_.size() : cap;
-        std::vector<Request*> batch(queue_.begin(), queue_.begin() + static_cast<long>(n));
-        queue_.erase(queue_.begin(), queue_.begin() + static_cast<long>(n));
         lk.unlock();
-        Run(batch);
-        lk.lock();
-        busy_ = false;
-        stats_.batches++;
-        if (static_cast<long long>(n) > stats_.largest) stats_.largest = static_cast<long long>(n);
-        for (Request* q : batch) q->done = true;
-        finished_.notify_all();            // the served threads leave; one parked thread becomes the next leader
+        Batch* b = new Batch();
+        b->reqs.push_back(&r);
+        RunNow(b);
+        Finish(b, &r);
+    } else {
+        r.slot = next_slot_;
+        next_slot_ = (next_slot_ + 1) % kSlots;
+        queue_.push_back(&r);
+        while (r.state == kParked) cv_[r.slot].wait(lk);
+        const State st = r.state;
+        Batch* b = r.batch;
+        lk.unlock();
+        if (st == kWait) {
+            AwaitTicket(b);
+            Finish(b, &r);
+        } else if (st == kLead) {
+            RunNow(b);
+            Finish(b, &r);
+        }
     }
     if (error) *error = r.error;
     return r.rc;
 }
 
-void BatchScheduler::Run(std::vector<Request*>& batch) {
+void BatchScheduler::Finish(Batch* b, Request* self) {
+    // 1. everything that parked meanwhile becomes the next batch and goes to the GPU before anybody is woken
+    Batch* next = nullptr;
+    bool slots[kSlots] = {};
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stats_.batches++;
+        if (static_cast<long long>(b->reqs.size()) > stats_.largest) stats_.largest = static_cast<long long>(b->reqs.size());
+        if (queue_.empty()) {
+            busy_ = false;
+        } else {
+            const size_t cap = static_cast<size_t>(g_max_batch.load());
+            const size_t n = queue_.size() < cap ? queue_.size() : cap;
+            next = new Batch();
+            next->reqs.assign(queue_.begin(), queue_.begin() + static_cast<long>(n));
+            queue_.erase(queue_.begin(), queue_.begin() + static_cast<long>(n));
+        }
+        for (Request* q : b->reqs)
+            if (q != self) { q->state = kDone; slots[q->slot] = true; }       // (rc and error were written before)
+    }
+    const bool submitted = next && Submit(next);
+    // 2. the finished batch's threads leave — unless the next batch still waits for somebody to run it
+    // (a request is its thread's stack: once its state is published it may be gone — nothing of it is read afterwards)
+    Request* heir = next ? next->reqs[0] : nullptr;
+    auto appoint = [&](State st) {
+        int slot;
+        { std::lock_guard<std::mutex> lk(mu_); slot = heir->slot; heir->batch = next; heir->state = st; }
+        cv_[slot].notify_all();
+    };
+    if (heir && !submitted) appoint(kLead);
+    for (int i = 0; i < kSlots; ++i)
+        if (slots[i]) cv_[i].notify_all();
+    // 3. one thread of the submitted batch waits for it
+    if (heir && submitted) appoint(kWait);
+    delete b;
+}
+
+bool BatchScheduler::Submit(Batch* b) {
+    const size_t n = b->reqs.size();
+    std::vector<fe_stream*> ss(n);
+    std::vector<const float*> ins(n);
+    std::vector<float*> outs(n);
+    std::vector<long long> nfr(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Request* r = b->reqs[i];
+        if (!r->s) return false;
+        ss[i] = r->s;
+        ins[i] = r->in;
+        outs[i] = r->out;
+        nfr[i] = r->frames;
+    }
+    return fe_batch_submit(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(), &b->ticket) == 0;
+}
+
+void BatchScheduler::AwaitTicket(Batch* b) {
+    const int rc = fe_ticket_wait(b->ticket);
+    b->ticket = nullptr;
+    const std::string msg = rc != 0 ? fe_last_error() : "";
+    for (Request* r : b->reqs) {
+        r->rc = rc;
+        if (rc != 0) r->error = msg;
+    }
+}
+
+void BatchScheduler::RunNow(Batch* b) {
+    std::vector<Request*>& batch = b->reqs;
     const int n = static_cast<int>(batch.size());
     if (n == 1) {
         Request* r = batch[0];

@@ -6,9 +6,13 @@
 // The GPU of a device serves one launch chain at a time, so concurrent calls queue anyway; this
 // class turns that queue into batches ("combining"): a thread that finds its GPU idle runs its own
 // block at once — no hand-off, no collection window, nothing added to a lone stream's latency —
-// and while it is in flight every other thread's block is parked; whoever finishes takes ALL
-// parked blocks with it as ONE fe_batch_process call.  Batches form exactly when there is
-// contention and grow with it.  No dispatcher thread exists, so there is nothing to join at exit.
+// and while a batch is on the GPU every other thread's block is parked.  The thread that sees a batch
+// complete first SUBMITS all parked blocks as the next batch (fe_batch_submit: the kernels are enqueued,
+// nobody waits yet), then wakes the threads of the finished batch, then one thread of the new batch,
+// which waits for its ticket and does the same in turn.  The GPU therefore never waits for a sleeping
+// thread to wake up (50 - 100 us, which used to be a third of every round with 64 file threads); the
+// wake-ups happen while the next batch runs.  Batches form exactly when there is contention and grow
+// with it.  No dispatcher thread exists, so there is nothing to join at exit.
 // Results are bit-identical to unbatched calls (same kernels, same per-stream arithmetic).
 #pragma once
 
@@ -47,22 +51,45 @@ public:
     Stats stats();
 
 private:
+    // What a parked thread is told when it is woken.
+    enum State {
+        kParked = 0,
+        kDone,      // your block has been computed: take rc and leave
+        kWait,      // your batch is on the GPU: wait for its ticket, then finish the batch
+        kLead       // your batch could not be submitted ahead: run it yourself, then finish it
+    };
+    struct Batch;
     struct Request {
         fe_stream* s;
         const float* in;
         int frames;
         float* out;
         int rc;
-        bool done;
         std::string error;
+        State state;            // under mu_
+        Batch* batch;           // with kWait / kLead
+        int slot;               // which of cv_ this thread sleeps on
     };
+    struct Batch {
+        std::vector<Request*> reqs;
+        fe_ticket* ticket = nullptr;
+    };
+    static const int kSlots = 64;
+
     BatchScheduler() {}
-    void Run(std::vector<Request*>& batch);
+    void RunNow(Batch* b);                       // synchronous engine call(s) for b
+    bool Submit(Batch* b);                       // fe_batch_submit; false: not possible, nothing enqueued
+    void AwaitTicket(Batch* b);                  // fe_ticket_wait, status into the requests
+    void Finish(Batch* b, Request* self);        // next batch to the GPU, wake b's threads, appoint the next batch's thread
 
     std::mutex mu_;
-    std::condition_variable finished_;
+    // Parked threads sleep on one of a few condition variables owned by the scheduler (not by the
+    // request, whose thread may be gone the moment it is released): a wake-up reaches the threads of
+    // one slot, not all parked threads.
+    std::condition_variable cv_[kSlots];
+    int next_slot_ = 0;
     std::vector<Request*> queue_;
-    bool busy_ = false;
+    bool busy_ = false;         // a batch is on the GPU or being run: new blocks park
     Stats stats_;
 };
 

@@ -44,7 +44,8 @@ enum {
     FE_ERR_PARAM = -2,   /* bad argument */
     FE_ERR_ALLOC = -3,   /* host or device allocation failed */
     FE_ERR_DEVICE = -4,  /* no usable HIP device / HIP runtime error */
-    FE_ERR_BUSY = -5
+    FE_ERR_BUSY = -5,
+    FE_ERR_UNSUPPORTED = -6  /* the call's fast form does not apply to these arguments; use the general one */
 };
 
 /* flags for fe_batch_process */
@@ -138,6 +139,17 @@ long long fe_stream_blocks_done(const fe_stream *s);
  * buffers (hipHostMalloc, hipHostRegister) let both bus directions run at once. */
 int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
                      float *const *out, int flags);
+
+/* The same in two steps, for host buffers that lie in page-locked memory bound to their streams
+ * (fe_stream_bind_host_buffer; otherwise FE_ERR_UNSUPPORTED and nothing is enqueued): submit enqueues the
+ * kernels and returns at once with a ticket; fe_ticket_wait returns when the outputs are in the callers'
+ * buffers, and consumes the ticket.  A host can keep one batch running while it assembles and submits the
+ * next (folve_amd/csrc/host/batch_scheduler.cpp does): batches execute in submission order.  A stream may
+ * be in one submitted batch at a time, and a ticket must be waited for before its streams are closed. */
+typedef struct fe_ticket fe_ticket;
+int fe_batch_submit(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
+                    float *const *out, fe_ticket **ticket);
+int fe_ticket_wait(fe_ticket *ticket);
 
 /* Running peaks of n streams with one synchronisation (what the batcher hands back per block). */
 int fe_batch_get_peaks(fe_stream *const *streams, int n, float *peak_signed, float *peak_abs);

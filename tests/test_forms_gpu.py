@@ -268,3 +268,79 @@ def test_injected_failure_leaves_stream_state(tuned, oracle):
     y_b = st.process_blocks(x[P:])
     ref = flt.open_stream(4).process_blocks(x)
     assert np.array_equal(np.concatenate([y_a, y_b]), ref)
+
+
+def test_submit_wait_split_matches_the_synchronous_call(tuned, oracle):
+    """fe_batch_submit / fe_ticket_wait (what the per-GPU combiner keeps the GPU busy with): two batches of
+    one-block calls on bound page-locked buffers submitted back to back, waited for afterwards — the same bits
+    as the synchronous calls; buffers that are not bound are refused with FE_ERR_UNSUPPORTED and nothing runs."""
+    import ctypes
+    L = fa.lib()
+    size, C, S = 60000, 2, 6
+    rng = np.random.default_rng(99)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+    sp, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+    P = flt.block_size
+    nblk = 4
+    xs = [rng.uniform(-1, 1, (nblk * P, C)).astype(np.float32) for _ in range(S)]
+    bufs, arrs = [], []
+    for _ in range(S):
+        b = ctypes.c_void_p()
+        assert L.fe_host_alloc(P * C * 4, ctypes.byref(b)) == 0
+        bufs.append(b)
+        arrs.append(np.ctypeslib.as_array(ctypes.cast(b, ctypes.POINTER(ctypes.c_float)), shape=(P, C)))
+
+    def arrays(streams, idx):
+        n = len(idx)
+        ss = (ctypes.c_void_p * n)(*[streams[i].h for i in idx])
+        pp = (ctypes.c_void_p * n)(*[bufs[i].value for i in idx])
+        nn = (ctypes.c_longlong * n)(*([P] * n))
+        return ss, pp, nn
+
+    try:
+        # synchronous reference: one fe_batch_process per block over all streams
+        ref_streams = [flt.open_stream(1) for _ in range(S)]
+        for s, b in zip(ref_streams, bufs):
+            assert L.fe_stream_bind_host_buffer(s.h, b, P * C * 4) == 0
+        ref = [[] for _ in range(S)]
+        for k in range(nblk):
+            for i in range(S):
+                arrs[i][:] = xs[i][k * P:(k + 1) * P]
+            ss, pp, nn = arrays(ref_streams, list(range(S)))
+            assert L.fe_batch_process(ss, S, pp, nn, pp, 0) == 0
+            for i in range(S):
+                ref[i].append(arrs[i].copy())
+        # two halves submitted back to back, then waited for
+        streams = [flt.open_stream(1) for _ in range(S)]
+        for s, b in zip(streams, bufs):
+            assert L.fe_stream_bind_host_buffer(s.h, b, P * C * 4) == 0
+        halves = [list(range(0, S // 2)), list(range(S // 2, S))]
+        for k in range(nblk):
+            for i in range(S):
+                arrs[i][:] = xs[i][k * P:(k + 1) * P]
+            tickets = []
+            for idx in halves:
+                ss, pp, nn = arrays(streams, idx)
+                t = ctypes.c_void_p()
+                assert L.fe_batch_submit(ss, len(idx), pp, nn, pp, ctypes.byref(t)) == 0 and t.value
+                tickets.append(t)
+            for t in tickets:
+                assert L.fe_ticket_wait(t) == 0
+            for i in range(S):
+                assert np.array_equal(arrs[i], ref[i][k]), (k, i)
+        y64 = oracle.linear_convolution_f64(xs[0], dense_taps(paths, size), C)
+        assert _rms(np.concatenate(ref[0]) - y64) <= TOL
+        # an ordinary numpy buffer is not bound: refused, nothing enqueued, the stream does not advance
+        before = streams[0].blocks_done()
+        plain = np.zeros((P, C), np.float32)
+        ss = (ctypes.c_void_p * 1)(streams[0].h)
+        pp = (ctypes.c_void_p * 1)(plain.ctypes.data)
+        nn = (ctypes.c_longlong * 1)(P)
+        t = ctypes.c_void_p()
+        assert L.fe_batch_submit(ss, 1, pp, nn, pp, ctypes.byref(t)) == -6 and not t.value
+        assert streams[0].blocks_done() == before
+        for s in streams + ref_streams:
+            s.close()
+    finally:
+        for b in bufs:
+            L.fe_host_free(b)

@@ -3,6 +3,8 @@
 // (/root/reference/convolve-file-handler.cc:335-347,370-424): FillBuffer -> WriteProcessed (which runs Process()).
 // Prints blocks per second over all threads, the latency of a block as a thread sees it, and what the per-GPU
 // combiner made of the calls.   usage: dropin_threads <filter.conf> <threads> <blocks per thread> <batching 0|1>
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -72,6 +74,16 @@ int main(int argc, char** argv) {
            "combiner: %lld calls in %lld launches (largest %lld); ok %d\n",
            nthreads, batching, blocks / dt, blocks * P * cout / dt / 1e6, cout, all[all.size() / 2], all[all.size() * 99 / 100],
            r1 - r0, b1 - b0, l1, ok);
+    // with the TRACE build of the library (make -C folve_amd/csrc TRACE=1; LD_LIBRARY_PATH / rpath to it): where the
+    // host's time between two engine calls goes
+    typedef int (*host_times_fn)(unsigned long long*, int);
+    if (host_times_fn ht = (host_times_fn)dlsym(RTLD_DEFAULT, "fe_debug_host_times")) {
+        unsigned long long v[8] = {};
+        ht(v, 0);
+        const double n = v[2] ? (double)v[2] : 1.0;
+        printf("   engine calls %llu: entry -> launches enqueued %.1f us, -> completion seen %.1f us, completion -> next engine call entered %.1f us\n",
+               v[2], v[0] / n / 1e3, v[1] / n / 1e3, v[4] / (n > 1 ? n - 1 : 1) / 1e3);
+    }
     for (auto* p : procs) fh_processor_destroy(p);
     return ok ? 0 : 1;
 }

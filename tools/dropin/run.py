@@ -23,7 +23,7 @@ with open(os.path.join(d, "filter-44100.conf"), "w") as f:
 exe = "/tmp/dropin_threads"
 subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"),
                        os.path.join(ROOT, "tools", "dropin", "dropin_threads.cpp"), "-o", exe,
-                       "-L" + os.path.join(ROOT, "folve_amd"), "-lfolve_amd", "-Wl,-rpath," + os.path.join(ROOT, "folve_amd")])
+                       "-L" + os.path.join(ROOT, "folve_amd"), "-lfolve_amd", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "folve_amd")])
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 for nt in (1, 2, 4, 8, 16, 32, 64, 128):
     for batching in (1, 0):
