@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void walk(const v2f* X, v2f* Y, int T, int row
     if (tile_major & 1) x = X + ((long)unit * 32 + tile) * rows_x * 256 + threadIdx.x;
     else x = X + (long)unit * rows_x * P + tile * 256 + threadIdx.x;
     if (tile_major & 2) y = Y + ((long)unit * 32 + tile) * T * 256 + threadIdx.x;
-    else y = Y + (long)unit * T * P + tile * 256 + threadIdx.x;
+    else y = Y + (long)unit * T * ystride + tile * 256 + threadIdx.x;      // (ystride = P, or P + padding)
     v2f w[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) w[d] = *(const GL v2f*)(x + d * xstride);
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     const int S = 128, T = argc > 1 ? atoi(argv[1]) : 64, RX = argc > 2 ? atoi(argv[2]) : 96;
     const long P = 8192;
     v2f *X, *Y;
-    hipMalloc(&X, (size_t)S * RX * P * 8); hipMalloc(&Y, (size_t)S * T * P * 8);
+    hipMalloc(&X, (size_t)S * RX * P * 8); hipMalloc(&Y, (size_t)S * T * (P + 1024) * 8);
     hipMemset(X, 0, (size_t)S * RX * P * 8);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     {
@@ -103,6 +103,19 @@ int main(int argc, char** argv) {
             const double bytes = (double)S * P * 8 * (T + 8) + (double)S * P * 8 * T;
             printf("spin=%2d %s: %.3f ms, %.2f TB/s\n", spin, tm == 0 ? "X rows, Y rows (64 KiB stride)" : tm == 1 ? "X tiles (2 KiB stride), Y rows" : tm == 2 ? "X rows, Y tiles" : "X tiles, Y tiles", best, bytes / best / 1e9);
         }
+    }
+    // Y rows with a padded stride: are 64 KiB-apart 2 KiB pieces an unlucky pattern for the HBM channels?
+    for (int pad : {0, 32, 64, 256, 512, 1024}) {
+        float best = 1e9;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(walk<8>, dim3(32, S), dim3(256), 50 * 1024, 0, X, Y, T, RX, (long)P, (long)(P + pad), 0, 0);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) best = ms;
+        }
+        const double bytes = (double)S * P * 8 * (T + 8) + (double)S * P * 8 * T;
+        printf("Y row stride P + %4d elements: %.3f ms, %.2f TB/s\n", pad, best, bytes / best / 1e9);
     }
     for (int wgs : {3, 6}) {
         float best = 1e9;
