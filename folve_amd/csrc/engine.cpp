@@ -89,7 +89,7 @@ struct fe_engine {
     hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ticket_events;   // idle completion events of fe_batch_submit tickets
     // profiling
-    bool fail_next_round = false;        // test hook: the next launch round fails with FE_ERR_DEVICE
+    int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none)
     bool profiling = false;
     hipEvent_t pev[4] = {};
     long long prof_launches[FE_K_COUNT] = {};
@@ -266,8 +266,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     }
 
     const bool prof = e->profiling;
-    if (e->fail_next_round) {           // test hook (fe_engine_set_tuning FE_TUNE_FAIL_NEXT): an injected device failure
-        e->fail_next_round = false;
+    if (e->fail_round_in > 0 && --e->fail_round_in == 0) {   // test hook (fe_engine_set_tuning FE_TUNE_FAIL_NEXT): an injected device failure
         return fail(FE_ERR_DEVICE, "injected device failure (test hook)");
     }
     fk::Tuning tn = e->tuning;
@@ -1106,7 +1105,8 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             e->tuning.fft_form = value;
             return FE_OK;
         case FE_TUNE_FAIL_NEXT:
-            e->fail_next_round = value != 0;
+            if (value < 0) return fail(FE_ERR_PARAM, "round count must be >= 0");
+            e->fail_round_in = value;
             return FE_OK;
         default:
             return fail(FE_ERR_PARAM, "unknown tuning knob %d", knob);

@@ -48,7 +48,7 @@ void BatchScheduler::ReleaseEngine(fe_engine* engine) {
 }
 
 int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error) {
-    Request r{s, in, valid_frames, out, 0, std::string(), kParked, nullptr, 0};
+    Request r{s, in, valid_frames, out, 0, std::string(), false, kParked, nullptr, 0};
     std::unique_lock<std::mutex> lk(mu_);
     stats_.requests++;
     if (!busy_) {
@@ -130,7 +130,22 @@ bool BatchScheduler::Submit(Batch* b) {
         outs[i] = r->out;
         nfr[i] = r->frames;
     }
-    return fe_batch_submit(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(), &b->ticket) == 0;
+    std::vector<long long> before(n);
+    for (size_t i = 0; i < n; ++i) before[i] = fe_stream_blocks_done(ss[i]);
+    const int rc = fe_batch_submit(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(), &b->ticket);
+    if (rc == 0) return true;
+    // Not submitted (buffers not bound, or a launch round refused).  Streams of an earlier round of the same
+    // call have consumed their block: they are settled with the error; the others are run by RunNow.
+    const std::string msg = fe_last_error();
+    for (size_t i = 0; i < n; ++i) {
+        Request* r = b->reqs[i];
+        if (fe_stream_blocks_done(r->s) != before[i]) {
+            r->rc = rc;
+            r->error = "block consumed by a batch that failed later: " + msg;
+            r->settled = true;
+        }
+    }
+    return false;
 }
 
 void BatchScheduler::AwaitTicket(Batch* b) {
@@ -144,8 +159,11 @@ void BatchScheduler::AwaitTicket(Batch* b) {
 }
 
 void BatchScheduler::RunNow(Batch* b) {
-    std::vector<Request*>& batch = b->reqs;
+    std::vector<Request*> batch;
+    for (Request* r : b->reqs)
+        if (!r->settled) batch.push_back(r);
     const int n = static_cast<int>(batch.size());
+    if (n == 0) return;
     if (n == 1) {
         Request* r = batch[0];
         r->rc = fe_stream_process(r->s, r->in, r->frames, r->out, NULL, NULL);
@@ -163,15 +181,26 @@ void BatchScheduler::RunNow(Batch* b) {
         outs[static_cast<size_t>(i)] = r->out;
         nfr[static_cast<size_t>(i)] = r->frames;
     }
+    std::vector<long long> before(batch.size());
+    for (int i = 0; i < n; ++i) before[static_cast<size_t>(i)] = fe_stream_blocks_done(ss[static_cast<size_t>(i)]);
     const int rc = fe_batch_process(ss.data(), n, ins.data(), nfr.data(), outs.data(), FE_HOST_PTRS);
     if (rc == 0) {
         for (Request* r : batch) r->rc = 0;
         return;
     }
-    // The batch was refused as a whole (a launch round that fails leaves its streams where they
-    // were): run the blocks one by one so that one bad stream does not fail its neighbours, and
-    // every block gets its own status and message.
-    for (Request* r : batch) {
+    const std::string msg = fe_last_error();
+    // The batch was refused.  A launch round that fails leaves its streams where they were: those blocks
+    // are run one by one, so that one bad stream does not fail its neighbours and every block gets its own
+    // status and message.  Streams of an EARLIER round of the same call (another filter's group) have
+    // consumed their block, but its output may never have been fetched: they fail with the batch's error
+    // rather than run the block twice.
+    for (int i = 0; i < n; ++i) {
+        Request* r = batch[static_cast<size_t>(i)];
+        if (fe_stream_blocks_done(r->s) != before[static_cast<size_t>(i)]) {
+            r->rc = rc;
+            r->error = "block consumed by a batch that failed later: " + msg;
+            continue;
+        }
         r->rc = fe_stream_process(r->s, r->in, r->frames, r->out, NULL, NULL);
         if (r->rc != 0) r->error = fe_last_error();
     }

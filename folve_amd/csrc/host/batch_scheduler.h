@@ -66,6 +66,7 @@ private:
         float* out;
         int rc;
         std::string error;
+        bool settled;           // rc is final already (its block was consumed by a submission that failed later)
         State state;            // under mu_
         Batch* batch;           // with kWait / kLead
         int slot;               // which of cv_ this thread sleeps on

@@ -164,7 +164,7 @@ enum {
     FE_TUNE_INV_RUN = 1,   /* K3 walker: consecutive blocks per workgroup */
     FE_TUNE_MAC_FORM = 2,  /* K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk */
     FE_TUNE_FFT_FORM = 3,  /* K1/K3: 1 general kernels only, 2 walkers whenever the shape allows */
-    FE_TUNE_FAIL_NEXT = 4  /* fault injection: the next launch round of this engine fails with FE_ERR_DEVICE */
+    FE_TUNE_FAIL_NEXT = 4  /* fault injection: the n-th launch round of this engine from now fails with FE_ERR_DEVICE (1 = the next) */
 };
 int fe_engine_set_tuning(fe_engine *e, int knob, int value);
 /* Device self-test of the cross-lane exchange the FFT rows use (kernels.h launch_xlane_selftest). */

@@ -270,6 +270,33 @@ def test_injected_failure_leaves_stream_state(tuned, oracle):
     assert np.array_equal(np.concatenate([y_a, y_b]), ref)
 
 
+def test_failure_in_a_later_group_of_a_batch(tuned, oracle):
+    """A batch over streams of two filters is launched group by group.  When the SECOND group's round is refused
+    (fault injection: the 2nd launch round from now), the call fails, the first group's streams have consumed
+    their block and the second's have not — which is what a caller (the per-GPU combiner) tells apart with
+    fe_stream_blocks_done before it retries anything."""
+    rng = np.random.default_rng(8)
+    flts = []
+    for size in (20000, 30000):
+        paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+        flts.append(make_pair(tuned, oracle, 2, 2, size, paths)[1])
+    P = flts[0].block_size
+    sa, sb = flts[0].open_stream(2), flts[1].open_stream(2)
+    x = rng.uniform(-1, 1, (2 * P, 2)).astype(np.float32)
+    fa.batch_process([sa, sb], [x[:P], x[:P]])
+    da, db = sa.blocks_done(), sb.blocks_done()
+    tuned.set_tuning(fail_next=2)
+    with pytest.raises(fa.FolveError) as err:
+        fa.batch_process([sa, sb], [x[P:], x[P:]])
+    assert err.value.code == -4
+    moved = (sa.blocks_done() - da, sb.blocks_done() - db)
+    assert sorted(moved) == [0, 1], moved                             # exactly one group ran
+    # the group that did not run repeats its block as if nothing had happened
+    late = sb if moved[1] == 0 else sa
+    ref = (flts[1] if late is sb else flts[0]).open_stream(2).process_blocks(x)
+    assert np.array_equal(late.process_blocks(x[P:]), ref[P:])
+
+
 def test_submit_wait_split_matches_the_synchronous_call(tuned, oracle):
     """fe_batch_submit / fe_ticket_wait (what the per-GPU combiner keeps the GPU busy with): two batches of
     one-block calls on bound page-locked buffers submitted back to back, waited for afterwards — the same bits
