@@ -1,0 +1,52 @@
+"""CPU: the host-side arithmetic of bench.py — the byte formulas its roofline block prints,
+the CPU count its baseline leg runs on, the power / clock reader.  No GPU, nothing under oracle/."""
+import importlib.util
+import os
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_algorithmic_bytes_are_the_survey_figures():
+    """bytes per block-channel = 12 P + 8 (P+1)(K_eff+1) + 8 (P+1) K_eff / S.
+    cfg3/cfg5 (K = 32, S = 64): 2 294 028; cfg1 (K = 8, S = 1): 1 212 552; cfg4 (K = 64, S = 1): 8 553 480."""
+    b = _bench()
+    assert int(b.alg_bytes(8192, 32, 64)["total"]) == 2294028
+    assert int(b.alg_bytes(8192, 8, 1)["total"]) == 1212552
+    assert int(b.alg_bytes(8192, 64, 1)["total"]) == 8553480
+    ab = b.alg_bytes(8192, 32, 64)
+    assert ab["mac"] == 8 * 8193 * 32 + 8 * 8193 * 32 / 64          # K2's share: K rows of the stream + the shared filter
+    # a T-block call needs at least 8P(T+K)/T + 8P in K2 (every row once, plus the K rows of history): a ninth of that
+    tb = b.tiled_bytes(8192, 32, 256)
+    assert tb["mac"] == 8 * 8192 * (256 + 32) / 256 + 8 * 8192 and tb["mac"] < ab["mac"] / 8
+    assert tb["total"] == tb["forward"] + tb["mac"] + tb["inverse"]
+
+
+def test_usable_cpus_is_bounded_by_the_affinity_mask():
+    b = _bench()
+    n, host, why = b.usable_cpus()
+    assert 1 <= n <= host and n <= len(os.sched_getaffinity(0)) and why in ("affinity mask", "cgroup CPU quota")
+
+
+def test_power_reader_on_a_fake_hwmon_tree(tmp_path):
+    b = _bench()
+    h = tmp_path / "hwmon" / "hwmon3"
+    h.mkdir(parents=True)
+    (h / "power1_input").write_text("1400000000\n")
+    (h / "power1_cap").write_text("1400000000\n")
+    (h / "freq1_input").write_text("1690000000\n")
+    (tmp_path / "pp_dpm_sclk").write_text("0: 500Mhz\n1: 1690Mhz *\n2: 2400Mhz\n")
+    w = b.PowerWatch.__new__(b.PowerWatch)
+    w.dirs, w.by_address, w.samples, w._thread, w._stop = [str(h)], False, [], None, None
+    with w:
+        time.sleep(0.25)
+    s = w.summary()
+    assert s["socket_w"] == 1400.0 and s["cap_w"] == 1400.0 and s["sclk_mhz"] == 1690.0
+    assert s["sclk_max_mhz"] == 2400 and s["at_power_cap"] is True and s["samples"] >= 3
