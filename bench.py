@@ -28,6 +28,8 @@ contract's keys:
                  per block, algorithmic and moved bytes coincide
   end_to_end   — the same batch from page-locked HOST buffers, PCIe inside the timed region
   single_block_us — one synchronous stereo block through fe_stream_process (the drop-in call)
+  drop_in_threads — the same call from 1 / 16 / 64 host threads at once, each its own folve::SoundProcessor
+                 (a C++ child process over include/folve_host.h), with and without the per-GPU combiner
   cpu_baseline — the CPU restatement of zita-convolver's algorithm (oracle/, rebuilt -march=native
                  on this box), all cores and one core, on a bounded sample (N = 1 only)
 """
@@ -509,6 +511,43 @@ def main():
         except Exception as e:  # noqa: BLE001
             single = {"error": repr(e)}
 
+    # ---- the drop-in call under load: N file threads, each its own folve::SoundProcessor pulling single blocks as
+    # ConvolveFileHandler does — a C++ host over include/folve_host.h (tools/dropin/dropin_threads.cpp, built by
+    # __graft_entry__.build()), run as a child process; the same filter through the real loader (.conf + WAV) ----
+    drop_in = None
+    if extras:
+        try:
+            import subprocess
+            import tempfile
+            exe = os.path.join(ROOT, "tools", "dropin", "dropin_threads")
+            if not os.path.exists(exe):
+                raise RuntimeError("tools/dropin/dropin_threads not built (python -c 'import __graft_entry__ as g; g.build()')")
+            d = tempfile.mkdtemp(prefix="folve_dropin_")
+            ir = np.stack(taps, axis=1).astype(np.float64)
+            ir16 = np.round(ir / np.abs(ir).max() * 0.9 * 32767).astype("<i2")
+            with open(os.path.join(d, "ir.wav"), "wb") as f:           # 16-bit PCM WAV, as the demo filters' impulse files
+                data = ir16.tobytes()
+                f.write(b"RIFF" + (36 + len(data)).to_bytes(4, "little") + b"WAVEfmt " + (16).to_bytes(4, "little") +
+                        (1).to_bytes(2, "little") + (C).to_bytes(2, "little") + (FS).to_bytes(4, "little") +
+                        (FS * C * 2).to_bytes(4, "little") + (C * 2).to_bytes(2, "little") + (16).to_bytes(2, "little") +
+                        b"data" + len(data).to_bytes(4, "little") + data)
+            with open(os.path.join(d, "filter-44100.conf"), "w") as f:
+                f.write("/convolver/new %d %d 256 %d\n" % (C, C, size))
+                for c in range(C):
+                    f.write("/impulse/read %d %d 2e-3 0 0 0 %d ir.wav\n" % (c + 1, c + 1, c + 1))
+            runs = []
+            for nt, comb in ((1, 1), (16, 1), (64, 1), (64, 0)):
+                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), "300", str(comb), "json"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                runs.append(json.loads(line[-1]) if line else {"threads": nt, "combiner": bool(comb), "error": "rc %d" % r.returncode})
+            drop_in = {"what": "N host threads, each a folve::SoundProcessor (page-locked block buffer, per-GPU combiner) "
+                               "pulling 8192-frame stereo blocks: FillBuffer -> WriteProcessed, 300 blocks per thread, K = %d; "
+                               "child process, tools/dropin/dropin_threads.cpp" % K,
+                       "usable_cpus": usable_cpus()[0], "runs": runs}
+        except Exception as e:  # noqa: BLE001
+            drop_in = {"error": repr(e)}
+
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as O      # CPU restatement: the baseline being reported, not the product
@@ -556,6 +595,7 @@ def main():
             "roofline_streaming": streaming,
             "end_to_end": end_to_end,
             "single_block": single,
+            "drop_in_threads": drop_in,
             "cpu_baseline": cpu,
         }
         if world > 1:

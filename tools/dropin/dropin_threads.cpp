@@ -2,7 +2,7 @@
 // the host classes, include/folve_host.h), each pulling 8192-frame blocks the way ConvolveFileHandler does
 // (/root/reference/convolve-file-handler.cc:335-347,370-424): FillBuffer -> WriteProcessed (which runs Process()).
 // Prints blocks per second over all threads, the latency of a block as a thread sees it, and what the per-GPU
-// combiner made of the calls.   usage: dropin_threads <filter.conf> <threads> <blocks per thread> <batching 0|1>
+// combiner made of the calls.   usage: dropin_threads <filter.conf> <threads> <blocks per thread> <batching 0|1> [json]
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -70,6 +71,14 @@ int main(int argc, char** argv) {
     const double blocks = (double)nthreads * nblocks;
     int ok = 1;
     for (auto* p : procs) ok &= fh_processor_ok(p);
+    if (argc > 5 && std::string(argv[5]) == "json") {
+        printf("{\"threads\": %d, \"combiner\": %s, \"blocks_per_s\": %.0f, \"msamples_per_s\": %.1f, \"block_latency_us_median\": %.1f, "
+               "\"block_latency_us_p99\": %.1f, \"engine_calls\": %lld, \"largest_batch\": %lld, \"ok\": %s}\n",
+               nthreads, batching ? "true" : "false", blocks / dt, blocks * P * cout / dt / 1e6, all[all.size() / 2], all[all.size() * 99 / 100],
+               b1 - b0, l1, ok ? "true" : "false");
+        for (auto* p : procs) fh_processor_destroy(p);
+        return ok ? 0 : 1;
+    }
     printf("threads %3d batching %d: %9.0f blocks/s = %7.1f Msamples/s (%d ch), block latency median %6.1f us, p99 %7.1f us; "
            "combiner: %lld calls in %lld launches (largest %lld); ok %d\n",
            nthreads, batching, blocks / dt, blocks * P * cout / dt / 1e6, cout, all[all.size() / 2], all[all.size() * 99 / 100],

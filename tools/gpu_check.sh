@@ -13,3 +13,8 @@ print("roofline", {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "
 print("single", d["single_block"]); print("e2e", d["end_to_end"]); print("cpu", d["cpu_baseline"])
 PY
 tail -3 gpurun_out/bench_driver_like.err
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench_driver_like.json").read().strip().splitlines()[-1])
+print("drop_in", json.dumps(d.get("drop_in_threads"))[:900])
+PY
