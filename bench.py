@@ -536,14 +536,20 @@ def main():
                 for c in range(C):
                     f.write("/impulse/read %d %d 2e-3 0 0 0 %d ir.wav\n" % (c + 1, c + 1, c + 1))
             runs = []
-            for nt, comb in ((1, 1), (16, 1), (64, 1), (64, 0)):
-                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), "300", str(comb), "json"],
-                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+            # (threads, combiner, run-ahead depth in blocks): depth 1 is the reference's one block per Process() call
+            for nt, comb, ra in ((1, 1, 1), (1, 1, 32), (16, 1, 32), (64, 1, 1), (64, 1, 32), (64, 1, 128), (64, 0, 1)):
+                nblk = 300 if ra == 1 else (20000 if nt == 1 else 4096 if nt <= 16 else 2048)
+                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), str(nblk), str(comb), "json",
+                                    "run_ahead=%d" % ra],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=180)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                runs.append(json.loads(line[-1]) if line else {"threads": nt, "combiner": bool(comb), "error": "rc %d" % r.returncode})
-            drop_in = {"what": "N host threads, each a folve::SoundProcessor (page-locked block buffer, per-GPU combiner) "
-                               "pulling 8192-frame stereo blocks: FillBuffer -> WriteProcessed, 300 blocks per thread, K = %d; "
-                               "child process, tools/dropin/dropin_threads.cpp" % K,
+                runs.append(json.loads(line[-1]) if line else {"threads": nt, "combiner": bool(comb), "run_ahead": ra,
+                                                               "error": "rc %d" % r.returncode})
+            drop_in = {"what": "N host threads, each a folve::SoundProcessor (page-locked ring, per-GPU combiner) pulling 8192-frame "
+                               "stereo blocks as ConvolveFileHandler::AddMoreSoundData does: FillBuffer -> WriteProcessed over "
+                               "sf_readf_float / sf_writef_float-shaped callbacks that copy every block in and out, K = %d; "
+                               "run_ahead = blocks a processor reads ahead of its reader (1 = the reference's one block per "
+                               "Process() call); child process, tools/dropin/dropin_threads.cpp" % K,
                        "usable_cpus": usable_cpus()[0], "runs": runs}
         except Exception as e:  # noqa: BLE001
             drop_in = {"error": repr(e)}

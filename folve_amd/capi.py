@@ -11,9 +11,9 @@ _LIB = None
 
 FE_HOST_PTRS, FE_DEVICE_PTRS, FE_ASYNC = 0, 1, 2
 FE_K_FORWARD, FE_K_MAC, FE_K_INVERSE, FE_K_COUNT = 0, 1, 2, 3
-FE_TUNE_FWD_RUN, FE_TUNE_INV_RUN, FE_TUNE_MAC_FORM, FE_TUNE_FFT_FORM, FE_TUNE_FAIL_NEXT = 0, 1, 2, 3, 4
+FE_TUNE_FWD_RUN, FE_TUNE_INV_RUN, FE_TUNE_MAC_FORM, FE_TUNE_FFT_FORM, FE_TUNE_FAIL_NEXT, FE_TUNE_LANES = 0, 1, 2, 3, 4, 5
 TUNE_KNOBS = {"fwd_run": FE_TUNE_FWD_RUN, "inv_run": FE_TUNE_INV_RUN, "mac_form": FE_TUNE_MAC_FORM,
-              "fft_form": FE_TUNE_FFT_FORM, "fail_next": FE_TUNE_FAIL_NEXT}
+              "fft_form": FE_TUNE_FFT_FORM, "fail_next": FE_TUNE_FAIL_NEXT, "lanes": FE_TUNE_LANES}
 KERNEL_NAMES = ("forward", "mac", "inverse")
 
 
@@ -71,9 +71,13 @@ ENGINE_SYMBOLS = [
     ("fe_stream_get_peaks", _i, [_vp, C.POINTER(_f), C.POINTER(_f)]),
     ("fe_stream_reset_peaks", _i, [_vp]),
     ("fe_stream_blocks_done", _ll, [_vp]),
+    ("fe_stream_block_size", _i, [_vp]),
+    ("fe_stream_max_blocks", _i, [_vp]),
     ("fe_batch_process", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _i]),
     ("fe_batch_submit", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _pvp]),
     ("fe_ticket_wait", _i, [_vp]),
+    ("fe_ticket_done", _i, [_vp]),
+    ("fe_device_local_cpulist", _i, [_i, C.c_char_p, C.c_size_t]),
     ("fe_batch_get_peaks", _i, [_pvp, _i, C.POINTER(_f), C.POINTER(_f)]),
     ("fe_engine_set_tuning", _i, [_vp, _i, _i]),
     ("fe_debug_xlane", _i, [_vp, _vp]),

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -57,6 +58,24 @@ struct DevTmp {
 struct TableOffsets { int o[4]; int total; };
 
 constexpr int kMaxChunks = 8;     // measured on cfg3: 2 chunks 4.9 ms, 4: 4.2, 8: 3.9, 16: 8.9 (launches too small)
+constexpr int kLanes = 2;
+
+// A launch lane: a HIP stream with its own K2 scratch.  Synchronous and device-pointer calls run on lane 0
+// (the engine's stream); fe_batch_submit puts a batch on the lane with the least outstanding work, so that
+// two submitted batches of DIFFERENT streams overlap on the GPU — K1 of one reads its PCM over the bus
+// while K3 of the other writes its results back (PCIe is full duplex; one lane uses one direction at a time).
+// A stream's consecutive calls must still execute in order: every stream remembers the lane and the
+// sequence number of its last call, and a call on the other lane first waits (on the device) for that
+// lane unless the earlier call is already known to have completed.
+struct Lane {
+    hipStream_t st = nullptr;
+    float2* Y = nullptr;                 // batch scratch: accumulated spectra of one launch round
+    size_t Y_bytes = 0;
+    hipEvent_t xev = nullptr;            // "everything submitted to this lane so far", for cross-lane ordering
+    long long submitted = 0;             // calls enqueued on this lane
+    long long done = 0;                  // ... of which known to have completed (a lane executes in order)
+    int outstanding = 0;                 // tickets not yet waited for
+};
 
 struct fe_engine {
     std::atomic<int> refs{1};     // creator + one per live filter (streams hold their filter)
@@ -66,8 +85,8 @@ struct fe_engine {
     std::mutex mu;
     std::map<int, float2*> tw;              // log2P -> [exp(-2 pi i k / 2P), k < 2P | stage A | stage B tables]
     std::map<int, TableOffsets> tw_off;
-    float2* Y = nullptr;                 // batch scratch: accumulated spectra of one launch round
-    size_t Y_bytes = 0;
+    Lane lanes[kLanes];                  // lanes[0].st == stream
+    int lane_toggle = 0;
     fk::Tuning tuning;                   // launch-shape overrides (fe_engine_set_tuning)
     bool host_io = false;                // the call in progress runs zero-copy on page-locked host buffers
     // rotating pinned/device buffers for job descriptors (async uploads)
@@ -89,7 +108,8 @@ struct fe_engine {
     hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ticket_events;   // idle completion events of fe_batch_submit tickets
     // profiling
-    int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none)
+    int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none, < 0: every round)
+    bool tuning_single_lane = false;     // FE_TUNE_LANES = 1: every submitted batch on lane 0 (measurements)
     bool profiling = false;
     hipEvent_t pev[4] = {};
     long long prof_launches[FE_K_COUNT] = {};
@@ -99,6 +119,8 @@ struct fe_engine {
 struct fe_ticket {                  // a submitted batch whose outputs are not yet known to be in the caller's buffers
     fe_engine* e = nullptr;          // (holds a reference)
     hipEvent_t ev = nullptr;
+    int lane = 0;
+    long long seq = 0;               // the lane's sequence number of this batch
 };
 
 struct PathHost {
@@ -134,6 +156,8 @@ struct fe_stream {
     unsigned int* peaks = nullptr; // [2]
     long long blocks_done = 0;
     int slot0 = 0;
+    int last_lane = -1;              // lane and sequence number of the last call that touched this stream's state
+    long long last_seq = 0;
     // page-locked caller memory bound to this stream (fe_stream_bind_host_buffer): calls whose
     // buffers lie inside it are read and written by the kernels directly, over the bus
     const char* bound_host = nullptr;
@@ -175,9 +199,9 @@ int get_twiddles(fe_engine* e, int log2P, fk::FftTables* out) {
     return FE_OK;
 }
 
-int ensure_bytes(fe_engine* e, void** ptr, size_t* have, size_t need) {
+int ensure_bytes(fe_engine* e, void** ptr, size_t* have, size_t need, hipStream_t user = nullptr) {
     if (*have >= need) return FE_OK;
-    HIP_TRY(hipStreamSynchronize(e->stream));   // nothing in flight may still use the old buffer
+    HIP_TRY(hipStreamSynchronize(user ? user : e->stream));   // nothing in flight may still use the old buffer
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     *have = 0;
@@ -197,8 +221,9 @@ struct Item {
 // One launch round over streams that share a filter.  Host-side stream state (ring position, block
 // count) advances only after all three launches were accepted: a failed round leaves every stream
 // where it was.
-int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any) {
-    hipStream_t st = e->stream;
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane) {
+    Lane& L = e->lanes[lane];
+    hipStream_t st = L.st;
     const int P = f->P;
     std::vector<fk::StreamJob> jobs;
     std::vector<Item*> owners;
@@ -231,7 +256,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     *any = !jobs.empty();
     if (jobs.empty()) return FE_OK;
 
-    int rc = ensure_bytes(e, (void**)&e->Y, &e->Y_bytes, (size_t)yunits * P * sizeof(float2));
+    int rc = ensure_bytes(e, (void**)&L.Y, &L.Y_bytes, (size_t)yunits * P * sizeof(float2), st);
     if (rc) return rc;
 
     // upload the descriptors through a rotating pinned buffer; a slot is reused only after the round
@@ -245,7 +270,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     const size_t bytes = jobs.size() * sizeof(fk::StreamJob);
     if (e->jobs_cap[slot] < bytes) {
         if (e->jobs_host[slot]) HIP_TRY(hipHostFree(e->jobs_host[slot]));
-        if (e->jobs_dev[slot]) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->jobs_dev[slot])); }
+        if (e->jobs_dev[slot]) HIP_TRY(hipFree(e->jobs_dev[slot]));    // (its last reader has finished: the slot's event, above)
         e->jobs_host[slot] = nullptr; e->jobs_dev[slot] = nullptr; e->jobs_cap[slot] = 0;
         const size_t cap = std::max<size_t>(bytes * 2, 64 * sizeof(fk::StreamJob));
         HIP_TRY(hipHostMalloc((void**)&e->jobs_host[slot], cap, hipHostMallocDefault));
@@ -266,7 +291,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     }
 
     const bool prof = e->profiling;
-    if (e->fail_round_in > 0 && --e->fail_round_in == 0) {   // test hook (fe_engine_set_tuning FE_TUNE_FAIL_NEXT): an injected device failure
+    if (e->fail_round_in < 0 || (e->fail_round_in > 0 && --e->fail_round_in == 0)) {   // test hook (fe_engine_set_tuning FE_TUNE_FAIL_NEXT): an injected device failure
         return fail(FE_ERR_DEVICE, "injected device failure (test hook)");
     }
     fk::Tuning tn = e->tuning;
@@ -275,9 +300,9 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
-    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, e->Y, max_blocks, f->mac_shape, tn, st));
+    HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, L.Y, max_blocks, f->mac_shape, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
-    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, e->Y, out_pairs_ok, tn, st));
+    HIP_TRY(fk::launch_inverse(dj, nj, max_blocks, f->dev, L.Y, out_pairs_ok, tn, st));
     HIP_TRY(hipEventRecord(e->jobs_ev[slot], st));
     e->jobs_ev_pending[slot] = true;
     if (prof) {
@@ -306,7 +331,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
 
 // Launch rounds for streams [i0, i1) of a call, grouped by filter; each group runs until its
 // frames are consumed.
-int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int i0, int i1) {
+int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int i0, int i1, int lane = 0) {
     std::vector<char> done((size_t)(i1 - i0), 0);
     for (int i = i0; i < i1; ++i) {
         if (done[(size_t)(i - i0)]) continue;
@@ -314,10 +339,17 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         std::vector<Item> group;
         for (int k = i; k < i1; ++k)
             if (!done[(size_t)(k - i0)] && streams[k]->f == f) { group.push_back(all[(size_t)k]); done[(size_t)(k - i0)] = 1; }
-        bool any = true;
+        bool any = true, enqueued = i > i0;
         while (any) {
-            int rc = launch_round(e, f, group, &any);
-            if (rc) return rc;
+            int rc = launch_round(e, f, group, &any, lane);
+            if (rc) {
+                // Kernels of earlier rounds of this call are already on the GPU and still write into the
+                // callers' buffers: the error is reported only after they have drained, so that a caller
+                // who is told "failed" owns its buffers again (best effort: the device may be gone).
+                if (enqueued) (void)hipStreamSynchronize(e->lanes[lane].st);
+                return rc;
+            }
+            enqueued = true;
         }
     }
     return FE_OK;
@@ -405,7 +437,9 @@ static unsigned long long host_now_ns() {
 // peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
                    const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr,
-                   hipEvent_t submit_event = nullptr) {
+                   hipEvent_t submit_event = nullptr, int lane = 0, long long* seq_out = nullptr) {
+    Lane& L = e->lanes[lane];
+    const hipStream_t st = L.st;
     bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
     const bool async = device_ptrs && (flags & FE_ASYNC);
     HOST_T(t_entry);
@@ -468,6 +502,29 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         in_floats += ((size_t)nframes[i] * s->f->ninp + 3) & ~(size_t)3;
         out_floats += ((size_t)nframes[i] * s->f->nout + 3) & ~(size_t)3;
     }
+    // A stream whose last call ran on the other lane and is not known to have completed: this lane waits
+    // (on the device) for everything that lane holds so far.  One wait per call covers all such streams.
+    {
+        bool waited[kLanes] = {};
+        for (int i = 0; i < n; ++i) {
+            const fe_stream* s = streams[i];
+            const int ol = s->last_lane;
+            if (ol < 0 || ol == lane || waited[ol] || s->last_seq <= e->lanes[ol].done) continue;
+            HIP_TRY(hipEventRecord(e->lanes[ol].xev, e->lanes[ol].st));
+            HIP_TRY(hipStreamWaitEvent(st, e->lanes[ol].xev, 0));
+            waited[ol] = true;
+        }
+    }
+    const long long seq = L.submitted + 1;
+    if (seq_out) *seq_out = seq;
+    // (whatever happens below, kernels of this call may have been enqueued: the streams belong to this lane now)
+    struct LaneScope {
+        Lane& L; fe_stream* const* streams; int n; int lane; long long seq;
+        ~LaneScope() {
+            L.submitted = seq;
+            for (int i = 0; i < n; ++i) { streams[i]->last_lane = lane; streams[i]->last_seq = seq; }
+        }
+    } lane_scope{L, streams, n, lane, seq};
     if (!device_ptrs) {
         int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
         if (rc) return rc;
@@ -484,7 +541,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         }
     }
     // worth pipelining: several streams and enough bytes that the bus time dwarfs the extra events
-    const bool pipelined = !device_ptrs && !e->profiling && n >= 4 &&
+    const bool pipelined = lane == 0 && !device_ptrs && !e->profiling && n >= 4 &&
                            (in_floats + out_floats) * sizeof(float) >= ((size_t)16 << 20);
     if (pipelined) {
         int rc = run_pipelined(e, streams, n, in, out, nframes, all);
@@ -493,25 +550,25 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         if (!device_ptrs) {
             for (int i = 0; i < n; ++i) {
                 const size_t ni = (size_t)nframes[i] * streams[i]->f->ninp;
-                if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, e->stream));
+                if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, st));
             }
         }
-        int rc = run_groups(e, streams, all, 0, n);
+        int rc = run_groups(e, streams, all, 0, n, lane);
         if (rc) return rc;
         if (!device_ptrs) {
             for (int i = 0; i < n; ++i) {
                 const size_t no = (size_t)nframes[i] * streams[i]->f->nout;
-                if (no) HIP_TRY(hipMemcpyAsync(out[i], stage_out_of[(size_t)i], no * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                if (no) HIP_TRY(hipMemcpyAsync(out[i], stage_out_of[(size_t)i], no * sizeof(float), hipMemcpyDeviceToHost, st));
             }
         }
     }
     if (peaks_out) {
         for (int i = 0; i < n; ++i)
             HIP_TRY(hipMemcpyAsync(peaks_out + 2 * i, streams[i]->peaks, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost,
-                                   e->stream));
+                                   st));
     }
     if (submit_event) {                  // fe_batch_submit: the caller waits on the ticket, not here
-        HIP_TRY(hipEventRecord(submit_event, e->stream));
+        HIP_TRY(hipEventRecord(submit_event, st));
         return FE_OK;
     }
     if (!async) {
@@ -520,7 +577,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             // The latency path: poll for completion instead of sleeping on the runtime's interrupt
             // (the wake-up costs more than the kernels); bounded, then the ordinary wait.
             for (int spin = 0; spin < 4000; ++spin) {
-                const hipError_t q = hipStreamQuery(e->stream);
+                const hipError_t q = hipStreamQuery(st);
 #ifdef FOLVE_PHASE_TRACE
                 if (q == hipSuccess) {
                     const unsigned long long t_done = host_now_ns();
@@ -529,13 +586,38 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
                     g_host_last_exit = t_done;
                 }
 #endif
-                if (q == hipSuccess) { (void)hipGetLastError(); return FE_OK; }   // (clears the sticky "not ready" of earlier polls)
+                if (q == hipSuccess) { (void)hipGetLastError(); L.done = seq; return FE_OK; }   // (clears the sticky "not ready" of earlier polls)
                 if (q != hipErrorNotReady) return fail(FE_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(q));
             }
             (void)hipGetLastError();
         }
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(st));
+        L.done = seq;
     }
+    return FE_OK;
+}
+
+// Before host-ordered work on lane 0 touches a stream's state (reset, peaks, close): order it behind the
+// stream's last call if that ran on another lane and is not known to have completed.
+int order_on_lane0(fe_engine* e, const fe_stream* s) {
+    const int ol = s->last_lane;
+    if (ol <= 0 || s->last_seq <= e->lanes[ol].done) return FE_OK;
+    HIP_TRY(hipEventRecord(e->lanes[ol].xev, e->lanes[ol].st));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->lanes[ol].xev, 0));
+    return FE_OK;
+}
+
+// The lane a submitted batch goes to: the one with fewer tickets outstanding, alternating on a tie.
+// Lane 1 is created on first use.
+int pick_lane(fe_engine* e, int* lane) {
+    if (!e->lanes[1].st) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->lanes[1].st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->lanes[1].xev, hipEventDisableTiming));
+    }
+    int l;
+    if (e->lanes[0].outstanding != e->lanes[1].outstanding) l = e->lanes[0].outstanding < e->lanes[1].outstanding ? 0 : 1;
+    else { l = e->lane_toggle; e->lane_toggle ^= 1; }
+    *lane = e->tuning_single_lane ? 0 : l;
     return FE_OK;
 }
 
@@ -586,6 +668,11 @@ int fe_engine_create(int device, void* hip_stream, fe_engine** out) {
         if (r != hipSuccess) { delete e; return fail(FE_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(r)); }
         e->own_stream = true;
     }
+    e->lanes[0].st = e->stream;
+    if (hipEventCreateWithFlags(&e->lanes[0].xev, hipEventDisableTiming) != hipSuccess) {
+        delete e;
+        return fail(FE_ERR_DEVICE, "hipEventCreate failed");
+    }
     for (int i = 0; i < kJobSlots; ++i) {
         if (hipEventCreateWithFlags(&e->jobs_ev[i], hipEventDisableTiming) != hipSuccess) {
             delete e;
@@ -603,9 +690,13 @@ static void engine_release(fe_engine* e) {
     if (!e) return;
     if (e->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
+    for (Lane& L : e->lanes) {
+        if (L.st) (void)hipStreamSynchronize(L.st);
+        if (L.Y) (void)hipFree(L.Y);
+        if (L.xev) (void)hipEventDestroy(L.xev);
+    }
+    if (e->lanes[1].st) (void)hipStreamDestroy(e->lanes[1].st);
     for (auto& kv : e->tw) (void)hipFree(kv.second);
-    if (e->Y) (void)hipFree(e->Y);
     if (e->cp_in) { (void)hipStreamSynchronize(e->cp_in); (void)hipStreamDestroy(e->cp_in); }
     if (e->cp_out) { (void)hipStreamSynchronize(e->cp_out); (void)hipStreamDestroy(e->cp_out); }
     for (int i = 0; i < kMaxChunks; ++i) {
@@ -633,12 +724,39 @@ void fe_engine_destroy(fe_engine* e) { engine_release(e); }
 
 int fe_engine_synchronize(fe_engine* e) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (Lane& L : e->lanes) {
+        if (!L.st) continue;
+        const long long upto = L.submitted;
+        HIP_TRY(hipStreamSynchronize(L.st));
+        L.done = upto;
+    }
     return FE_OK;
 }
 
 int fe_engine_device(const fe_engine* e) { return e ? e->device : -1; }
+
+int fe_device_local_cpulist(int device, char* buf, size_t size) {
+    if (!buf || size < 2) return fail(FE_ERR_PARAM, "bad buffer");
+    buf[0] = 0;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FE_ERR_DEVICE, "no PCI bus id for device %d", device);
+    }
+    for (char* p = bus; *p; ++p) *p = (char)tolower((unsigned char)*p);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE* fp = fopen(path, "r");
+    if (!fp) return fail(FE_ERR_UNSUPPORTED, "%s not readable", path);
+    const bool got = fgets(buf, (int)size, fp) != nullptr;
+    fclose(fp);
+    if (!got) return fail(FE_ERR_UNSUPPORTED, "%s is empty", path);
+    buf[strcspn(buf, "\r\n")] = 0;
+    if (!buf[0]) return fail(FE_ERR_UNSUPPORTED, "%s is empty", path);
+    return FE_OK;
+}
 
 // ---- filter ---------------------------------------------------------------
 int fe_filter_create(fe_engine* e, int ninp, int nout, int maxsize, float density, fe_filter** out) {
@@ -918,10 +1036,14 @@ int fe_stream_reset(fe_stream* s) {
     fe_engine* e = s->eng;
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    int rc = order_on_lane0(e, s);
+    if (rc) return rc;
     HIP_TRY(hipMemsetAsync(s->fdl, 0, s->fdl_bytes, e->stream));
     HIP_TRY(hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream));
     s->slot0 = 0;
     s->blocks_done = 0;
+    s->last_lane = 0;
+    s->last_seq = ++e->lanes[0].submitted;
     return FE_OK;
 }
 
@@ -932,6 +1054,7 @@ void fe_stream_close(fe_stream* s) {
         std::lock_guard<std::mutex> lk(e->mu);
         (void)hipSetDevice(e->device);
         (void)hipStreamSynchronize(e->stream);
+        if (s->last_lane > 0 && s->last_seq > e->lanes[s->last_lane].done) (void)hipStreamSynchronize(e->lanes[s->last_lane].st);
         (void)hipFree(s->fdl);
         (void)hipFree(s->peaks);
     }
@@ -945,6 +1068,8 @@ int fe_stream_get_peaks(fe_stream* s, float* peak_signed, float* peak_abs) {
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     unsigned int bits[2] = {0, 0};
+    int orc = order_on_lane0(e, s);
+    if (orc) return orc;
     HIP_TRY(hipMemcpyAsync(bits, s->peaks, sizeof(bits), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     float v[2];
@@ -964,6 +1089,8 @@ int fe_batch_get_peaks(fe_stream* const* streams, int n, float* peak_signed, flo
     std::vector<unsigned int> bits((size_t)n * 2, 0u);
     for (int i = 0; i < n; ++i) {
         if (!streams[i] || streams[i]->eng != e) return fail(FE_ERR_PARAM, "stream %d is null or on another engine", i);
+        int orc = order_on_lane0(e, streams[i]);
+        if (orc) return orc;
         HIP_TRY(hipMemcpyAsync(&bits[(size_t)i * 2], streams[i]->peaks, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost,
                                e->stream));
     }
@@ -982,11 +1109,17 @@ int fe_stream_reset_peaks(fe_stream* s) {
     fe_engine* e = s->eng;
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
+    int orc = order_on_lane0(e, s);
+    if (orc) return orc;
     HIP_TRY(hipMemsetAsync(s->peaks, 0, 2 * sizeof(unsigned int), e->stream));
+    s->last_lane = 0;
+    s->last_seq = ++e->lanes[0].submitted;
     return FE_OK;
 }
 
 long long fe_stream_blocks_done(const fe_stream* s) { return s ? s->blocks_done : 0; }
+int fe_stream_block_size(const fe_stream* s) { return s ? s->f->P : 0; }
+int fe_stream_max_blocks(const fe_stream* s) { return s ? s->max_blocks : 0; }
 
 int fe_batch_process(fe_stream* const* streams, int n, const float* const* in, const long long* nframes,
                      float* const* out, int flags) {
@@ -1008,7 +1141,12 @@ int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, co
     fe_ticket* t = new (std::nothrow) fe_ticket();
     if (!t) return fail(FE_ERR_ALLOC, "out of memory");
     std::lock_guard<std::mutex> lk(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
+    if (hipSetDevice(e->device) != hipSuccess) {
+        delete t;
+        return fail(FE_ERR_DEVICE, "hipSetDevice(%d) failed", e->device);
+    }
+    int lane = 0;
+    if (int lrc = pick_lane(e, &lane)) { delete t; return lrc; }
     if (!e->ticket_events.empty()) {
         t->ev = e->ticket_events.back();
         e->ticket_events.pop_back();
@@ -1017,23 +1155,37 @@ int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, co
         delete t;
         return fail(FE_ERR_DEVICE, "hipEventCreate failed");
     }
-    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev);
+    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev, lane, &t->seq);
     if (rc) {
-        e->ticket_events.push_back(t->ev);
+        e->ticket_events.push_back(t->ev);      // (never recorded: nothing pends on it)
         delete t;
         return rc;
     }
     t->e = e;
+    t->lane = lane;
+    e->lanes[lane].outstanding++;
     e->refs.fetch_add(1);
     *ticket = t;
     return FE_OK;
+}
+
+int fe_ticket_done(fe_ticket* t) {
+    if (!t) return fail(FE_ERR_PARAM, "null ticket");
+    const hipError_t q = hipEventQuery(t->ev);
+    (void)hipGetLastError();
+    if (q == hipSuccess) return 1;
+    if (q == hipErrorNotReady) return 0;
+    return fail(FE_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(q));
 }
 
 int fe_ticket_wait(fe_ticket* t) {
     if (!t) return fail(FE_ERR_PARAM, "null ticket");
     fe_engine* e = t->e;
     int rc = FE_OK;
-    if (hipSetDevice(e->device) != hipSuccess) rc = fail(FE_ERR_DEVICE, "hipSetDevice failed");
+    // (events can be waited for from any device context: a failing hipSetDevice does not excuse the wait —
+    //  the caller is about to be told that its buffers are its own again)
+    (void)hipSetDevice(e->device);
+    (void)hipGetLastError();
     // the latency path: poll (bounded), then the runtime's wait — as fe_stream_process does
     bool done = false;
     for (int spin = 0; rc == FE_OK && !done && spin < 4000; ++spin) {
@@ -1042,13 +1194,21 @@ int fe_ticket_wait(fe_ticket* t) {
         else if (q != hipErrorNotReady) rc = fail(FE_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(q));
     }
     (void)hipGetLastError();             // (clears the sticky "not ready" of the polls)
-    if (rc == FE_OK && !done) {
+    if (!done) {
         const hipError_t w = hipEventSynchronize(t->ev);
-        if (w != hipSuccess) rc = fail(FE_ERR_DEVICE, "hipEventSynchronize: %s", hipGetErrorString(w));
+        if (w != hipSuccess && rc == FE_OK) rc = fail(FE_ERR_DEVICE, "hipEventSynchronize: %s", hipGetErrorString(w));
+        if (w == hipSuccess) done = true;
     }
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        e->ticket_events.push_back(t->ev);
+        Lane& L = e->lanes[t->lane];
+        L.outstanding--;
+        if (done) {
+            if (t->seq > L.done) L.done = t->seq;
+            e->ticket_events.push_back(t->ev);
+        } else {
+            (void)hipEventDestroy(t->ev);        // may still be pending: never recycled
+        }
     }
     delete t;
     engine_release(e);
@@ -1104,9 +1264,12 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "FFT form must be 0, 1 or 2");
             e->tuning.fft_form = value;
             return FE_OK;
+        case FE_TUNE_LANES:
+            if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "lanes must be 0 (automatic), 1 or 2");
+            e->tuning_single_lane = value == 1;
+            return FE_OK;
         case FE_TUNE_FAIL_NEXT:
-            if (value < 0) return fail(FE_ERR_PARAM, "round count must be >= 0");
-            e->fail_round_in = value;
+            e->fail_round_in = value < 0 ? -1 : value;
             return FE_OK;
         default:
             return fail(FE_ERR_PARAM, "unknown tuning knob %d", knob);

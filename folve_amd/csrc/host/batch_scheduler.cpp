@@ -2,11 +2,23 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
-#include <memory>
 
 namespace folve {
+
+struct BatchScheduler::Request {
+    fe_stream* s = nullptr;
+    const float* in = nullptr;
+    long long frames = 0;
+    float* out = nullptr;
+    long long blocks = 0;
+    int rc = 0;
+    std::string error;
+    State state = kQueued;                  // under mu_
+    std::shared_ptr<Batch> batch;           // once taken out of the queue
+};
 
 namespace {
 std::atomic<int> g_enabled{-1};        // -1: not decided yet (environment)
@@ -47,163 +59,185 @@ void BatchScheduler::ReleaseEngine(fe_engine* engine) {
     Schedulers().erase(engine);
 }
 
-int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error) {
-    Request r{s, in, valid_frames, out, 0, std::string(), false, kParked, nullptr, 0};
+BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, long long frames, float* out) {
+    Request* r = new Request();
+    r->s = s;
+    r->in = in;
+    r->frames = frames;
+    r->out = out;
+    const int P = fe_stream_block_size(s);
+    r->blocks = P > 0 ? (frames + P - 1) / P : 0;
     std::unique_lock<std::mutex> lk(mu_);
     stats_.requests++;
-    if (!busy_) {
-        // The GPU is idle: this block runs at once, by itself (nothing can be parked while the GPU is idle).
-        busy_ = true;
-        lk.unlock();
-        Batch* b = new Batch();
-        b->reqs.push_back(&r);
-        RunNow(b);
-        Finish(b, &r);
-    } else {
-        r.slot = next_slot_;
-        next_slot_ = (next_slot_ + 1) % kSlots;
-        queue_.push_back(&r);
-        while (r.state == kParked) cv_[r.slot].wait(lk);
-        const State st = r.state;
-        Batch* b = r.batch;
-        lk.unlock();
-        if (st == kWait) {
-            AwaitTicket(b);
-            Finish(b, &r);
-        } else if (st == kLead) {
-            RunNow(b);
-            Finish(b, &r);
-        }
+    stats_.blocks += r->blocks;
+    queue_.push_back(r);
+    if (lanes_busy_ >= kLanes && !pumping_) {
+        // Both lanes taken.  If one of the batches has finished unobserved (its threads are all busy serving
+        // what they got earlier), retire it now so that the queue — this request included — moves on.
+        std::shared_ptr<Batch> finished;
+        for (const std::shared_ptr<Batch>& b : flying_)
+            if (b->ticket && !b->has_waiter && fe_ticket_done(b->ticket) == 1) { finished = b; break; }
+        if (finished) CompleteLocked(lk, finished);
     }
-    if (error) *error = r.error;
-    return r.rc;
+    PumpLocked(lk);
+    return r;
 }
 
-void BatchScheduler::Finish(Batch* b, Request* self) {
-    // 1. everything that parked meanwhile becomes the next batch and goes to the GPU before anybody is woken
-    Batch* next = nullptr;
-    bool slots[kSlots] = {};
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        stats_.batches++;
-        if (static_cast<long long>(b->reqs.size()) > stats_.largest) stats_.largest = static_cast<long long>(b->reqs.size());
-        if (queue_.empty()) {
-            busy_ = false;
-        } else {
-            const size_t cap = static_cast<size_t>(g_max_batch.load());
-            const size_t n = queue_.size() < cap ? queue_.size() : cap;
-            next = new Batch();
-            next->reqs.assign(queue_.begin(), queue_.begin() + static_cast<long>(n));
-            queue_.erase(queue_.begin(), queue_.begin() + static_cast<long>(n));
-        }
-        for (Request* q : b->reqs)
-            if (q != self) { q->state = kDone; slots[q->slot] = true; }       // (rc and error were written before)
-    }
-    const bool submitted = next && Submit(next);
-    // 2. the finished batch's threads leave — unless the next batch still waits for somebody to run it
-    // (a request is its thread's stack: once its state is published it may be gone — nothing of it is read afterwards)
-    Request* heir = next ? next->reqs[0] : nullptr;
-    auto appoint = [&](State st) {
-        int slot;
-        { std::lock_guard<std::mutex> lk(mu_); slot = heir->slot; heir->batch = next; heir->state = st; }
-        cv_[slot].notify_all();
-    };
-    if (heir && !submitted) appoint(kLead);
-    for (int i = 0; i < kSlots; ++i)
-        if (slots[i]) cv_[i].notify_all();
-    // 3. one thread of the submitted batch waits for it
-    if (heir && submitted) appoint(kWait);
-    delete b;
-}
-
-bool BatchScheduler::Submit(Batch* b) {
-    const size_t n = b->reqs.size();
-    std::vector<fe_stream*> ss(n);
-    std::vector<const float*> ins(n);
-    std::vector<float*> outs(n);
-    std::vector<long long> nfr(n);
-    for (size_t i = 0; i < n; ++i) {
-        const Request* r = b->reqs[i];
-        if (!r->s) return false;
-        ss[i] = r->s;
-        ins[i] = r->in;
-        outs[i] = r->out;
-        nfr[i] = r->frames;
-    }
-    std::vector<long long> before(n);
-    for (size_t i = 0; i < n; ++i) before[i] = fe_stream_blocks_done(ss[i]);
-    const int rc = fe_batch_submit(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(), &b->ticket);
-    if (rc == 0) return true;
-    // Not submitted (buffers not bound, or a launch round refused).  Streams of an earlier round of the same
-    // call have consumed their block: they are settled with the error; the others are run by RunNow.
-    const std::string msg = fe_last_error();
-    for (size_t i = 0; i < n; ++i) {
-        Request* r = b->reqs[i];
-        if (fe_stream_blocks_done(r->s) != before[i]) {
-            r->rc = rc;
-            r->error = "block consumed by a batch that failed later: " + msg;
-            r->settled = true;
+bool BatchScheduler::Ready(Request* r) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (r->state == kDone) return true;
+    if (r->state == kFlying) {
+        const std::shared_ptr<Batch> b = r->batch;
+        if (b->ticket && !b->has_waiter && fe_ticket_done(b->ticket) == 1) {
+            CompleteLocked(lk, b);
+            return r->state == kDone;
         }
     }
     return false;
 }
 
-void BatchScheduler::AwaitTicket(Batch* b) {
-    const int rc = fe_ticket_wait(b->ticket);
-    b->ticket = nullptr;
+int BatchScheduler::Wait(Request* r, std::string* error) {
+    std::unique_lock<std::mutex> lk(mu_);
+    while (r->state != kDone) {
+        if (r->state == kFlying) {
+            const std::shared_ptr<Batch> b = r->batch;
+            if (b->ticket && !b->has_waiter) CompleteLocked(lk, b);      // nobody waits for this batch yet: this thread does
+            else b->cv.wait(lk);                                          // (being submitted, or somebody else waits)
+            continue;
+        }
+        // still queued: both lanes are taken (or a pump is under way).  Help the oldest batch nobody waits for.
+        std::shared_ptr<Batch> help;
+        for (const std::shared_ptr<Batch>& b : flying_)
+            if (b->ticket && !b->has_waiter) { help = b; break; }
+        if (help) { CompleteLocked(lk, help); continue; }
+        if (!pumping_ && lanes_busy_ < kLanes) { PumpLocked(lk); continue; }
+        queue_cv_.wait(lk);
+    }
+    const int rc = r->rc;
+    if (error) *error = r->error;
+    lk.unlock();
+    delete r;
+    return rc;
+}
+
+int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error) {
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (queue_.empty() && lanes_busy_ == 0 && !pumping_) {
+            // The GPU is idle: this block runs at once, by itself, through the engine's synchronous latency path.
+            lanes_busy_++;
+            stats_.requests++;
+            stats_.blocks++;
+            stats_.batches++;
+            if (stats_.largest < 1) stats_.largest = 1;
+            lk.unlock();
+            const int rc = fe_stream_process(s, in, valid_frames, out, NULL, NULL);
+            if (rc != 0 && error) *error = fe_last_error();
+            lk.lock();
+            lanes_busy_--;
+            PumpLocked(lk);
+            return rc;
+        }
+    }
+    return Wait(Submit(s, in, valid_frames, out), error);
+}
+
+// Wait for b's ticket (outside the lock), settle its requests, put the next batch on the GPU, then wake b's threads.
+void BatchScheduler::CompleteLocked(std::unique_lock<std::mutex>& lk, const std::shared_ptr<Batch>& b) {
+    b->has_waiter = true;
+    fe_ticket* t = b->ticket;
+    lk.unlock();
+    const int rc = fe_ticket_wait(t);
     const std::string msg = rc != 0 ? fe_last_error() : "";
-    for (Request* r : b->reqs) {
-        r->rc = rc;
-        if (rc != 0) r->error = msg;
+    lk.lock();
+    b->ticket = nullptr;
+    for (Request* q : b->reqs) {
+        q->rc = rc;
+        if (rc != 0) q->error = msg;
+        q->state = kDone;                   // (a request is not touched by the scheduler after this: its thread may free it)
+    }
+    b->done = true;
+    flying_.erase(std::remove(flying_.begin(), flying_.end(), b), flying_.end());
+    lanes_busy_--;
+    PumpLocked(lk);                         // everything that queued up meanwhile leaves before anybody is woken
+    b->cv.notify_all();
+}
+
+void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
+    while (!pumping_ && lanes_busy_ < kLanes && !queue_.empty()) {
+        pumping_ = true;
+        const std::shared_ptr<Batch> b = std::make_shared<Batch>();
+        const size_t cap = static_cast<size_t>(g_max_batch.load());
+        const size_t n = std::min(queue_.size(), cap);
+        long long blocks = 0;
+        for (size_t i = 0; i < n; ++i) {
+            Request* r = queue_.front();
+            queue_.pop_front();
+            r->state = kFlying;
+            r->batch = b;
+            blocks += r->blocks;
+            b->reqs.push_back(r);
+        }
+        if (lanes_busy_ > 0) stats_.overlapped++;
+        lanes_busy_++;
+        stats_.batches++;
+        if (blocks > stats_.largest) stats_.largest = blocks;
+        lk.unlock();
+
+        // ---- outside the lock: the engine call (a few tens of microseconds of launches) ----
+        std::vector<fe_stream*> ss(n);
+        std::vector<const float*> ins(n);
+        std::vector<float*> outs(n);
+        std::vector<long long> nfr(n), before(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Request* r = b->reqs[i];
+            ss[i] = r->s;
+            ins[i] = r->in;
+            outs[i] = r->out;
+            nfr[i] = r->frames;
+            before[i] = fe_stream_blocks_done(r->s);
+        }
+        fe_ticket* ticket = nullptr;
+        const int rc = fe_batch_submit(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(), &ticket);
+        if (rc != 0) {
+            // Not submitted (a buffer outside its stream's bound memory, or a launch round refused).  A round that
+            // fails leaves its streams where they were: those requests run one by one, each with its own status, so
+            // that one bad stream does not fail its neighbours.  Streams of an EARLIER round of the same call
+            // (another filter's group) have consumed their blocks, whose output may be incomplete: they fail with
+            // the batch's error rather than run twice.  (The engine has drained that round before returning.)
+            const std::string msg = fe_last_error();
+            for (size_t i = 0; i < n; ++i) {
+                Request* r = b->reqs[i];
+                if (fe_stream_blocks_done(r->s) != before[i]) {
+                    r->rc = rc;
+                    r->error = "blocks consumed by a batch that failed later: " + msg;
+                } else {
+                    RunAlone(r);
+                }
+            }
+        }
+        lk.lock();
+        pumping_ = false;
+        if (rc == 0) {
+            b->ticket = ticket;
+            flying_.push_back(b);
+        } else {
+            for (Request* r : b->reqs) r->state = kDone;
+            b->done = true;
+            lanes_busy_--;
+        }
+        b->cv.notify_all();                 // threads that found their request "being submitted"
+        queue_cv_.notify_all();             // threads whose request has just left the queue
     }
 }
 
-void BatchScheduler::RunNow(Batch* b) {
-    std::vector<Request*> batch;
-    for (Request* r : b->reqs)
-        if (!r->settled) batch.push_back(r);
-    const int n = static_cast<int>(batch.size());
-    if (n == 0) return;
-    if (n == 1) {
-        Request* r = batch[0];
-        r->rc = fe_stream_process(r->s, r->in, r->frames, r->out, NULL, NULL);
-        if (r->rc != 0) r->error = fe_last_error();
-        return;
-    }
-    std::vector<fe_stream*> ss(batch.size());
-    std::vector<const float*> ins(batch.size());
-    std::vector<float*> outs(batch.size());
-    std::vector<long long> nfr(batch.size());
-    for (int i = 0; i < n; ++i) {
-        const Request* r = batch[static_cast<size_t>(i)];
-        ss[static_cast<size_t>(i)] = r->s;
-        ins[static_cast<size_t>(i)] = r->in;
-        outs[static_cast<size_t>(i)] = r->out;
-        nfr[static_cast<size_t>(i)] = r->frames;
-    }
-    std::vector<long long> before(batch.size());
-    for (int i = 0; i < n; ++i) before[static_cast<size_t>(i)] = fe_stream_blocks_done(ss[static_cast<size_t>(i)]);
-    const int rc = fe_batch_process(ss.data(), n, ins.data(), nfr.data(), outs.data(), FE_HOST_PTRS);
-    if (rc == 0) {
-        for (Request* r : batch) r->rc = 0;
-        return;
-    }
-    const std::string msg = fe_last_error();
-    // The batch was refused.  A launch round that fails leaves its streams where they were: those blocks
-    // are run one by one, so that one bad stream does not fail its neighbours and every block gets its own
-    // status and message.  Streams of an EARLIER round of the same call (another filter's group) have
-    // consumed their block, but its output may never have been fetched: they fail with the batch's error
-    // rather than run the block twice.
-    for (int i = 0; i < n; ++i) {
-        Request* r = batch[static_cast<size_t>(i)];
-        if (fe_stream_blocks_done(r->s) != before[static_cast<size_t>(i)]) {
-            r->rc = rc;
-            r->error = "block consumed by a batch that failed later: " + msg;
-            continue;
-        }
-        r->rc = fe_stream_process(r->s, r->in, r->frames, r->out, NULL, NULL);
-        if (r->rc != 0) r->error = fe_last_error();
-    }
+void BatchScheduler::RunAlone(Request* r) {
+    fe_stream* ss[1] = {r->s};
+    const float* ii[1] = {r->in};
+    float* oo[1] = {r->out};
+    long long nn[1] = {r->frames};
+    r->rc = fe_batch_process(ss, 1, ii, nn, oo, FE_HOST_PTRS);
+    if (r->rc != 0) r->error = fe_last_error();
 }
 
 BatchScheduler::Stats BatchScheduler::stats() {

@@ -1,22 +1,34 @@
-// batch_scheduler.h — coalesces per-file block requests into GPU batches, without a timer.
+// batch_scheduler.h — coalesces the block requests of many open files into GPU batches, without a timer.
 //
 // In folve every open file is pulled by its own thread: a FUSE worker in
 // ConversionBuffer::FillUntil (conversion-buffer.cc:151-163) or the BufferThread running ahead
-// of the reader (buffer-thread.cc:73-105), one 8192-frame block per SoundProcessor::Process call.
-// The GPU of a device serves one launch chain at a time, so concurrent calls queue anyway; this
-// class turns that queue into batches ("combining"): a thread that finds its GPU idle runs its own
-// block at once — no hand-off, no collection window, nothing added to a lone stream's latency —
-// and while a batch is on the GPU every other thread's block is parked.  The thread that sees a batch
-// complete first SUBMITS all parked blocks as the next batch (fe_batch_submit: the kernels are enqueued,
-// nobody waits yet), then wakes the threads of the finished batch, then one thread of the new batch,
-// which waits for its ticket and does the same in turn.  The GPU therefore never waits for a sleeping
-// thread to wake up (50 - 100 us, which used to be a third of every round with 64 file threads); the
-// wake-ups happen while the next batch runs.  Batches form exactly when there is contention and grow
-// with it.  No dispatcher thread exists, so there is nothing to join at exit.
-// Results are bit-identical to unbatched calls (same kernels, same per-stream arithmetic).
+// of the reader (buffer-thread.cc:73-105).  A SoundProcessor hands the combiner REQUESTS: a span of
+// consecutive blocks of its stream (one block for the reference's synchronous Process(), sound-processor.cc:98-127;
+// a run-ahead chunk of up to N blocks when the processor reads ahead of its reader, sound_processor.h).
+//
+// A request is submitted without waiting (Submit) and collected later (Wait); Process() is the two
+// back to back.  The combiner keeps at most kLanes batches on the GPU.  A request that finds a lane free
+// leaves at once as a batch of its own — nothing is ever added to a lone stream's latency, there is no
+// collection window and no dispatcher thread — and requests that arrive while both lanes are busy queue up;
+// whichever thread next sees a batch complete submits everything queued as the next batch BEFORE it wakes
+// anybody, so the GPU never waits for a sleeping thread.  Batches form exactly when there is contention and
+// grow with it.  Two batches in flight sit on the engine's two launch lanes (folve_engine.h,
+// fe_batch_submit): while one batch's K3 writes results to host memory, the other's K1 already reads its
+// PCM — both directions of the bus at work.
+//
+// The threads that wait are the only workers: a thread whose request is in a batch nobody waits for yet
+// becomes that batch's waiter (fe_ticket_wait), settles every request in it, submits the next batch and
+// wakes the others.
+//
+// Results do not depend on the combiner being on or off beyond float32 rounding: a stream's arithmetic is
+// the same, but the K1/K2/K3 launch forms are chosen from the batch shape, and forms differ in summation
+// order.  One-block requests that travel in batches of at most 64 blocks use the same forms
+// as a lone block and are bit-identical to it.
 #pragma once
 
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -28,10 +40,13 @@ namespace folve {
 class BatchScheduler {
 public:
     struct Stats {
-        long long requests = 0;     // blocks submitted
+        long long requests = 0;     // requests submitted
+        long long blocks = 0;       // blocks in them
         long long batches = 0;      // engine calls issued
-        long long largest = 0;      // most blocks in one call
+        long long largest = 0;      // most blocks in one engine call
+        long long overlapped = 0;   // batches submitted while another was still on the GPU
     };
+    struct Request;                 // a submitted span; owned by the scheduler until Wait returns
 
     // The scheduler serving `engine` (created on first use; freed by ReleaseEngine or at exit).
     static BatchScheduler* ForEngine(fe_engine* engine);
@@ -40,57 +55,46 @@ public:
     // (FOLVE_AMD_BATCH=0 in the environment does the same).
     static void SetEnabled(bool on);
     static bool Enabled();
-    // Upper bound of blocks per engine call.
+    // Upper bound of requests per engine call.
     static void Configure(int max_batch);
+
+    // Enqueue `frames` interleaved frames (ceil(frames / block) blocks, the last zero-padded) of stream `s`:
+    // never waits for the GPU.  `in` and `out` must lie in page-locked memory bound to the stream and stay
+    // untouched until Wait returns.  One request per stream at a time.
+    Request* Submit(fe_stream* s, const float* in, long long frames, float* out);
+    // Blocks until the request has been computed; returns the engine's status for THIS request and frees it.
+    int Wait(Request* r, std::string* error);
+    // True once Wait would not block.
+    bool Ready(Request* r);
 
     // One block for one stream, exactly fe_stream_process without the peaks (the caller scans its
     // own output, as sound-processor.cc:116-125 does); blocks until the block has been computed.
-    // Returns the engine's status for THIS block; *error receives the engine's message on failure.
     int Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error);
 
     Stats stats();
 
 private:
-    // What a parked thread is told when it is woken.
-    enum State {
-        kParked = 0,
-        kDone,      // your block has been computed: take rc and leave
-        kWait,      // your batch is on the GPU: wait for its ticket, then finish the batch
-        kLead       // your batch could not be submitted ahead: run it yourself, then finish it
-    };
-    struct Batch;
-    struct Request {
-        fe_stream* s;
-        const float* in;
-        int frames;
-        float* out;
-        int rc;
-        std::string error;
-        bool settled;           // rc is final already (its block was consumed by a submission that failed later)
-        State state;            // under mu_
-        Batch* batch;           // with kWait / kLead
-        int slot;               // which of cv_ this thread sleeps on
-    };
+    static const int kLanes = 2;
     struct Batch {
         std::vector<Request*> reqs;
         fe_ticket* ticket = nullptr;
+        bool has_waiter = false;
+        bool done = false;
+        std::condition_variable cv;             // the batch's other threads sleep here
     };
-    static const int kSlots = 64;
+    enum State { kQueued = 0, kFlying, kDone };
 
     BatchScheduler() {}
-    void RunNow(Batch* b);                       // synchronous engine call(s) for b
-    bool Submit(Batch* b);                       // fe_batch_submit; false: not possible, nothing enqueued
-    void AwaitTicket(Batch* b);                  // fe_ticket_wait, status into the requests
-    void Finish(Batch* b, Request* self);        // next batch to the GPU, wake b's threads, appoint the next batch's thread
+    void PumpLocked(std::unique_lock<std::mutex>& lk);                    // queue -> batches while a lane is free
+    void CompleteLocked(std::unique_lock<std::mutex>& lk, const std::shared_ptr<Batch>& b);   // wait for b's ticket, settle, pump
+    void RunAlone(Request* r);                                            // synchronous engine call for one request
 
     std::mutex mu_;
-    // Parked threads sleep on one of a few condition variables owned by the scheduler (not by the
-    // request, whose thread may be gone the moment it is released): a wake-up reaches the threads of
-    // one slot, not all parked threads.
-    std::condition_variable cv_[kSlots];
-    int next_slot_ = 0;
-    std::vector<Request*> queue_;
-    bool busy_ = false;         // a batch is on the GPU or being run: new blocks park
+    std::condition_variable queue_cv_;          // requests still queued sleep here until a pump takes them
+    std::deque<Request*> queue_;
+    std::vector<std::shared_ptr<Batch>> flying_;
+    int lanes_busy_ = 0;                        // batches on the GPU + batches being submitted + lone synchronous calls
+    bool pumping_ = false;                      // one thread at a time turns the queue into batches (keeps submission order)
     Stats stats_;
 };
 

@@ -8,6 +8,7 @@
 
 #include "batch_scheduler.h"
 #include "device_router.h"
+#include "numa_placement.h"
 #include "processor_pool.h"
 #include "sound_processor.h"
 #include "sstring.h"
@@ -27,11 +28,13 @@ public:
         memcpy(dst, src_, sizeof(float) * static_cast<size_t>(n) * ch_);
         src_ += static_cast<size_t>(n) * ch_;
         left_ -= n;
+        taken_ += n;
         return n;
     }
+    int taken() const { return taken_; }
 private:
     const float* src_;
-    int left_, ch_;
+    int left_, ch_, taken_ = 0;
 };
 
 class SpanSink : public folve::FrameSink {
@@ -45,6 +48,24 @@ public:
 private:
     float* dst_;
     int ch_;
+};
+
+class CallbackSource : public folve::FrameSource {
+public:
+    CallbackSource(fh_read_fn fn, void* user) : fn_(fn), user_(user) {}
+    int ReadFrames(float* dst, int frames) override { return fn_(user_, dst, frames); }
+private:
+    fh_read_fn fn_;
+    void* user_;
+};
+
+class CallbackSink : public folve::FrameSink {
+public:
+    CallbackSink(fh_write_fn fn, void* user) : fn_(fn), user_(user) {}
+    int WriteFrames(const float* src, int frames) override { return fn_(user_, src, frames); }
+private:
+    fh_write_fn fn_;
+    void* user_;
 };
 
 inline SoundProcessor* SP(fh_processor* p) { return reinterpret_cast<SoundProcessor*>(p); }
@@ -83,10 +104,27 @@ int fh_processor_fill_buffer(fh_processor* p, const float* src, int frames_avail
     SpanSource s(src, frames_available, SP(p)->input_channels());
     return SP(p)->FillBuffer(&s);
 }
+int fh_processor_fill_buffer2(fh_processor* p, const float* src, int frames_available, int* consumed) {
+    SpanSource s(src, frames_available, SP(p)->input_channels());
+    const int r = SP(p)->FillBuffer(&s);
+    if (consumed) *consumed = s.taken();
+    return r;
+}
 void fh_processor_write_processed(fh_processor* p, float* dst, int sample_count) {
     SpanSink s(dst, SP(p)->output_channels());
     SP(p)->WriteProcessed(&s, sample_count);
 }
+int fh_processor_fill_buffer_from(fh_processor* p, fh_read_fn read, void* user) {
+    CallbackSource s(read, user);
+    return SP(p)->FillBuffer(&s);
+}
+void fh_processor_write_processed_to(fh_processor* p, fh_write_fn write, void* user, int sample_count) {
+    CallbackSink s(write, user);
+    SP(p)->WriteProcessed(&s, sample_count);
+}
+void fh_run_ahead_set(int blocks) { SoundProcessor::SetRunAhead(blocks); }
+int fh_run_ahead_get(void) { return SoundProcessor::RunAhead(); }
+int fh_processor_run_ahead(const fh_processor* p) { return SP(p)->run_ahead(); }
 int fh_processor_is_input_buffer_complete(const fh_processor* p) { return SP(p)->is_input_buffer_complete(); }
 int fh_processor_pending_writes(const fh_processor* p) { return SP(p)->pending_writes(); }
 int fh_processor_input_channels(const fh_processor* p) { return SP(p)->input_channels(); }
@@ -132,18 +170,27 @@ int fh_batcher_process(fe_engine* engine, fe_stream* s, const float* in, int val
     return folve::BatchScheduler::ForEngine(engine)->Process(s, in, valid_frames, out, NULL);
 }
 void fh_batching_stats(long long* requests, long long* batches, long long* largest) {
-    long long r = 0, b = 0, l = 0;
+    fh_batching_stats2(requests, NULL, batches, largest, NULL);
+}
+void fh_batching_stats2(long long* requests, long long* blocks, long long* batches, long long* largest, long long* overlapped) {
+    long long r = 0, b = 0, l = 0, k = 0, o = 0;
     folve::DeviceRouter* router = folve::DeviceRouter::Default();
     for (int d = 0; d < router->device_count(); ++d) {
         fe_engine* e = router->EngineIfCreated(d);
         if (!e) continue;
         const folve::BatchScheduler::Stats st = folve::BatchScheduler::ForEngine(e)->stats();
         r += st.requests; b += st.batches; if (st.largest > l) l = st.largest;
+        k += st.blocks; o += st.overlapped;
     }
+    if (blocks) *blocks = k;
+    if (overlapped) *overlapped = o;
     if (requests) *requests = r;
     if (batches) *batches = b;
     if (largest) *largest = l;
 }
+
+void fh_numa_placement_set(int on) { folve::SetNumaPlacement(on != 0); }
+int fh_pin_thread_near_device(int device) { return folve::PinThreadNearDevice(device) ? 1 : 0; }
 
 int fh_router_device_count(void) { return folve::DeviceRouter::Default()->device_count(); }
 int fh_router_live_streams(int slot) { return folve::DeviceRouter::Default()->live_streams(slot); }

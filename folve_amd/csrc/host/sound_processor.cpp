@@ -1,3 +1,11 @@
+// sound_processor.cpp — the block machine of folve's SoundProcessor on top of the GPU engine.
+//
+// This file restates the interface and the FillBuffer / WriteProcessed / Process state machine of
+// folve's sound-processor.{h,cc}, Copyright (C) 2012 Henner Zeller <h.zeller@acm.org>, which is free
+// software under the GNU General Public License, version 3 or (at your option) any later version;
+// this restatement is distributed under the same terms, WITHOUT ANY WARRANTY.  See
+// <http://www.gnu.org/licenses/>.  The arithmetic underneath (the engine, its kernels) and the
+// run-ahead ring are original work.
 #include "sound_processor.h"
 
 #include <assert.h>
@@ -8,9 +16,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "batch_scheduler.h"
 #include "device_router.h"
+#include "numa_placement.h"
 
 namespace folve {
 
@@ -18,6 +28,23 @@ static time_t GetModificationTime(const std::string& filename) {
     struct stat st;
     if (stat(filename.c_str(), &st) != 0) return 0;
     return st.st_mtime;
+}
+
+namespace {
+std::atomic<int> g_run_ahead{-1};          // -1: not decided yet (environment)
+const int kMaxRunAhead = 1024;
+}  // namespace
+
+void SoundProcessor::SetRunAhead(int blocks) { g_run_ahead.store(std::max(1, std::min(blocks, kMaxRunAhead))); }
+
+int SoundProcessor::RunAhead() {
+    int v = g_run_ahead.load();
+    if (v < 0) {
+        const char* env = getenv("FOLVE_AMD_RUN_AHEAD");
+        v = env ? std::max(1, std::min(atoi(env), kMaxRunAhead)) : 32;
+        g_run_ahead.store(v);
+    }
+    return v;
 }
 
 SoundProcessor* SoundProcessor::Create(const std::string& config_file, int samplerate, int channels) {
@@ -50,16 +77,22 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
                                                            samplerate, channels, &zita);
     if (!filter) return NULL;
     fe_stream* stream = NULL;
-    // One block per call is the reference's contract; the ring is sized for run-ahead batches too.
-    static const int kMaxBlocksPerCall = 32;
-    const int rc = fe_stream_open(filter, kMaxBlocksPerCall, &stream);
+    // The stream's delay line is sized for the longest call this processor will make: its run-ahead depth
+    // (one block per call is the reference's contract and what depth 1 gives).
+    const int run_depth = RunAhead();
+    const int rc = fe_stream_open(filter, run_depth, &stream);
     fe_filter_release(filter);           // the stream holds its own reference
     if (rc != 0) {
         Logf("Cannot open a convolver stream for %s: %s", config_file.c_str(), fe_last_error());
         return NULL;
     }
     zita.engine = engine;
-    return new SoundProcessor(zita, config_file, stream);
+    if (NumaPlacement()) {
+        // page-locked pages land where the allocating thread runs: next to the GPU that will read them
+        ScopedDeviceAffinity near_gpu(fe_engine_device(engine));
+        return new SoundProcessor(zita, config_file, stream, run_depth);
+    }
+    return new SoundProcessor(zita, config_file, stream, run_depth);
 }
 
 // The block buffer (`buffer_`, sound-processor.cc:62-63: fragm * max(ninp, nout) floats, reused in
@@ -77,30 +110,154 @@ static float* AllocBlockBuffer(size_t floats, bool* pinned) {
     return new float[floats];
 }
 
-SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream)
+// Floats of one run-ahead chunk: `depth` blocks of input and of output; in place when the channel counts agree
+// (folve_engine.h: in-place calls of any length are fine then).
+static size_t ChunkFloats(const ZitaConfig& c, int depth) {
+    if (depth <= 1) return 0;
+    const size_t in = static_cast<size_t>(depth) * c.fragm * c.ninp, out = static_cast<size_t>(depth) * c.fragm * c.nout;
+    return c.ninp == c.nout ? in : in + out;
+}
+
+SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream, int run_depth)
     : zita_config_(config), config_file_(cfg), config_file_timestamp_(GetModificationTime(cfg)), stream_(stream),
+      run_depth_(run_depth),
       buffer_floats_(static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)),
-      buffer_(AllocBlockBuffer(buffer_floats_, &buffer_pinned_)),
+      arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth)),
+      buffer_(AllocBlockBuffer(arena_floats_, &buffer_pinned_)),
+      cur_(NULL), ahead_(NULL), ring_block_(NULL), tail_(NULL), tail_frames_(0), source_short_(false), depth_next_(1),
       input_pos_(0), output_pos_(0), max_out_value_observed_(0.0), max_abs_value_observed_(0.0), ok_(true) {
-    if (buffer_pinned_ && fe_stream_bind_host_buffer(stream_, buffer_, buffer_floats_ * sizeof(float)) != 0) {
+    if (buffer_pinned_ && fe_stream_bind_host_buffer(stream_, buffer_, arena_floats_ * sizeof(float)) != 0) {
         Logf("Processor %p: block buffer not bound (%s): blocks will be staged", static_cast<void*>(this), fe_last_error());
+    }
+    if (run_depth_ > 1) {
+        // [ block buffer | chunk 0 | chunk 1 ] in one page-locked allocation bound to the stream
+        float* p = buffer_ + buffer_floats_;
+        const size_t in = static_cast<size_t>(run_depth_) * config.fragm * config.ninp;
+        for (Chunk& c : chunks_) {
+            c.in = p;
+            c.out = config.ninp == config.nout ? p : p + in;
+            p += ChunkFloats(config, run_depth_);
+        }
+        tail_ = new float[static_cast<size_t>(config.fragm) * config.ninp];
     }
     Reset();
 }
 
 SoundProcessor::~SoundProcessor() {
+    DrainRing();                         // a request still on the GPU writes into the ring
     fe_stream_close(stream_);
     DeviceRouter::Default()->StreamClosed(zita_config_.engine);
     if (buffer_pinned_) fe_host_free(buffer_);
     else delete[] buffer_;
+    delete[] tail_;
 }
 
 int SoundProcessor::device() const { return fe_engine_device(zita_config_.engine); }
 
+// Ask the source for the next chunk (depth_next_ whole blocks).  Whole blocks stay in the chunk; frames beyond
+// the last whole block — the file's short last block — are moved to tail_.  A short read stops further
+// read-ahead until everything read so far has been handed out.
+bool SoundProcessor::ReadChunk(FrameSource* in, Chunk* c) {
+    const int P = zita_config_.fragm;
+    const int want = depth_next_ * P;
+    const int got = in->ReadFrames(c->in, want);
+    c->blocks = got / P;
+    c->next = 0;
+    const int rem = got - c->blocks * P;
+    if (rem > 0) {
+        memcpy(tail_, c->in + static_cast<size_t>(c->blocks) * P * input_channels(), sizeof(float) * rem * input_channels());
+        tail_frames_ = rem;
+    }
+    if (got < want) source_short_ = true;
+    depth_next_ = std::min(depth_next_ * 2, run_depth_);
+    return c->blocks > 0;
+}
+
+// One engine request for the chunk's blocks.  Through the combiner the call returns at once and the chunk is
+// collected by SettleChunk; with the combiner off the engine is called synchronously here.
+void SoundProcessor::SubmitChunk(Chunk* c) {
+    const long long frames = static_cast<long long>(c->blocks) * zita_config_.fragm;
+    if (BatchScheduler::Enabled()) {
+        c->request = BatchScheduler::ForEngine(zita_config_.engine)->Submit(stream_, c->in, frames, c->out);
+        return;
+    }
+    c->request = NULL;
+    const int rc = fe_stream_process_blocks(stream_, c->in, frames, c->out);
+    if (rc != 0) {
+        Logf("GPU convolution failed (%d): %s", rc, fe_last_error());
+        memset(c->out, 0, sizeof(float) * frames * output_channels());
+        ok_ = false;
+    }
+}
+
+void SoundProcessor::SettleChunk(Chunk* c) {
+    if (!c->request) return;
+    std::string error;
+    const int rc = BatchScheduler::ForEngine(zita_config_.engine)->Wait(static_cast<BatchScheduler::Request*>(c->request), &error);
+    c->request = NULL;
+    if (rc != 0) {
+        Logf("GPU convolution failed (%d): %s", rc, error.c_str());
+        memset(c->out, 0, sizeof(float) * static_cast<size_t>(c->blocks) * zita_config_.fragm * output_channels());
+        ok_ = false;                     // ProcessorPool::Return will not pool this processor
+    }
+}
+
+// Forget everything read ahead (Reset, destruction); a request still on the GPU is waited for first.
+void SoundProcessor::DrainRing() {
+    for (Chunk& c : chunks_) {
+        SettleChunk(&c);
+        c.blocks = c.next = 0;
+    }
+    cur_ = ahead_ = NULL;
+    ring_block_ = NULL;
+    tail_frames_ = 0;
+    source_short_ = false;
+    depth_next_ = 1;
+}
+
 int SoundProcessor::FillBuffer(FrameSource* in) {
-    const int samples_needed = zita_config_.fragm - input_pos_;
+    const int P = zita_config_.fragm;
+    const int samples_needed = P - input_pos_;
     assert(samples_needed);   // Otherwise, call WriteProcessed() first.
     output_pos_ = -1;
+    ring_block_ = NULL;
+    if (run_depth_ > 1 && input_pos_ == 0) {
+        // A fresh block: it comes out of the run-ahead ring if a whole block can be had.
+        if (!(cur_ && cur_->next < cur_->blocks)) {
+            cur_ = NULL;
+            if (ahead_) {                                   // the chunk computed while the last one was handed out
+                cur_ = ahead_;
+                ahead_ = NULL;
+            } else if (tail_frames_ == 0 && !source_short_) {
+                Chunk* c = &chunks_[0];
+                if (ReadChunk(in, c)) { SubmitChunk(c); cur_ = c; }
+            }
+            if (cur_) {
+                SettleChunk(cur_);                          // (one request per stream at a time)
+                // keep the GPU busy with the next chunk while this one is handed out block by block
+                if (tail_frames_ == 0 && !source_short_) {
+                    Chunk* c = cur_ == &chunks_[0] ? &chunks_[1] : &chunks_[0];
+                    if (ReadChunk(in, c)) { SubmitChunk(c); ahead_ = c; }
+                }
+            }
+        }
+        if (cur_) {
+            ring_block_ = cur_->out + static_cast<size_t>(cur_->next) * P * output_channels();
+            cur_->next++;
+            input_pos_ = P;
+            return P;
+        }
+        // No whole block left: what remains of the read-ahead is the file's short last block.  It goes into the
+        // block buffer unprocessed, exactly where the reference's FillBuffer would have put it.
+        source_short_ = false;
+        if (tail_frames_ > 0) {
+            const int r = tail_frames_;
+            memcpy(buffer_, tail_, sizeof(float) * r * input_channels());
+            tail_frames_ = 0;
+            input_pos_ = r;
+            return r;
+        }
+    }
     const int r = in->ReadFrames(buffer_ + static_cast<size_t>(input_pos_) * input_channels(), samples_needed);
     input_pos_ += r;
     return r;
@@ -111,11 +268,25 @@ void SoundProcessor::WriteProcessed(FrameSink* out, int sample_count) {
         Process();
     }
     assert(sample_count <= zita_config_.fragm - output_pos_);
-    out->WriteFrames(buffer_ + static_cast<size_t>(output_pos_) * output_channels(), sample_count);
+    const float* block = ring_block_ ? ring_block_ : buffer_;
+    out->WriteFrames(block + static_cast<size_t>(output_pos_) * output_channels(), sample_count);
     output_pos_ += sample_count;
     if (output_pos_ == zita_config_.fragm) {
         input_pos_ = 0;
     }
+}
+
+// The maximum over returned frames, signed as sound-processor.cc:120-123 compares, and the magnitude beside it.
+void SoundProcessor::ScanPeaks(const float* v, size_t n) {
+    float hi = max_out_value_observed_, mag = max_abs_value_observed_;
+    for (size_t j = 0; j < n; ++j) {
+        const float x = v[j];
+        hi = x > hi ? x : hi;
+        const float a = x < 0 ? -x : x;
+        mag = a > mag ? a : mag;
+    }
+    max_out_value_observed_ = hi;
+    max_abs_value_observed_ = mag;
 }
 
 // One block through the GPU.  The reference zero-fills the unread tail, splits
@@ -124,6 +295,12 @@ void SoundProcessor::WriteProcessed(FrameSink* out, int sample_count) {
 // the device — frames >= input_pos_ count as zero, input_pos_ frames come back —
 // and the maximum is taken here over the returned frames, signed as cc:120-123 does.
 void SoundProcessor::Process() {
+    if (ring_block_) {
+        // a block of the run-ahead ring: computed already (its chunk was settled when it became current)
+        if (ok_) ScanPeaks(ring_block_, static_cast<size_t>(input_pos_) * output_channels());
+        output_pos_ = 0;
+        return;
+    }
     if (input_pos_ > 0) {
         // The call goes through the device's combiner: alone it runs at once; while another file's
         // block is in flight on this GPU it is parked and leaves with the next batch.
@@ -141,15 +318,7 @@ void SoundProcessor::Process() {
             memset(buffer_, 0, sizeof(float) * n);
             ok_ = false;                 // ProcessorPool::Return will not pool this processor
         } else {
-            float hi = max_out_value_observed_, mag = max_abs_value_observed_;
-            for (size_t j = 0; j < n; ++j) {
-                const float v = buffer_[j];
-                hi = v > hi ? v : hi;
-                const float a = v < 0 ? -v : v;
-                mag = a > mag ? a : mag;
-            }
-            max_out_value_observed_ = hi;
-            max_abs_value_observed_ = mag;
+            ScanPeaks(buffer_, n);
         }
     }
     output_pos_ = 0;
@@ -166,6 +335,7 @@ void SoundProcessor::ResetMaxValues() {
 }
 
 void SoundProcessor::Reset() {
+    DrainRing();
     fe_stream_reset(stream_);
     input_pos_ = 0;
     output_pos_ = -1;

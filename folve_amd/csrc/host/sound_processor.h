@@ -8,6 +8,20 @@
 // compiled only where <sndfile.h> exists (the folve build); everything else — the block
 // machine itself — works on FrameSource / FrameSink (libsndfile's sf_readf_float /
 // sf_writef_float contract), so the library builds and is tested without libsndfile.
+//
+// Run-ahead (the reference's BufferThread goal arithmetic, buffer-thread.cc:34,73-105,
+// and the pull loop conversion-buffer.cc:151-163).  folve is file based and already converts ahead of its
+// reader; one 8192-frame block per engine call is far too little for a GPU.  A processor therefore reads
+// AHEAD of the block machine: when FillBuffer finds its ring empty it asks the source for up to N whole
+// blocks at once, hands them to the GPU as ONE multi-block request (through the per-GPU combiner, which
+// merges the requests of all open files), and serves FillBuffer / WriteProcessed block by block from the
+// ring with exactly the return values and state (`pending_writes`, `is_input_buffer_complete`) the
+// reference's calls produce (convolve-file-handler.cc:370-424).  Two chunks alternate: while the reader is
+// served from one, the other is on the GPU.  The depth ramps 1, 2, 4 .. N blocks, so the first block of a
+// file costs one block's latency.  Only WHOLE blocks run ahead: the short last block of a file stays in the
+// block buffer unprocessed, as in the reference, so that the gapless hand-over (PassoverProcessor,
+// convolve-file-handler.cc:328-351) can top it up from the next file — at that point the ring is empty by
+// construction.  max_output_value() advances block by block as blocks are handed out, not as they are computed.
 #pragma once
 
 #include <time.h>
@@ -45,6 +59,10 @@ public:
     static SoundProcessor* Create(const std::string& config_file, int samplerate, int channels);
     // Same, on a given engine (used by ProcessorPool's sharder).
     static SoundProcessor* CreateOn(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
+    // Blocks a processor may read ahead of its reader (1 = off: one block per engine call, the reference's
+    // pattern).  Applies to processors created afterwards.  Default 32, or FOLVE_AMD_RUN_AHEAD.
+    static void SetRunAhead(int blocks);
+    static int RunAhead();
 private:
     static SoundProcessor* CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
 public:
@@ -84,23 +102,48 @@ public:
     bool ConfigStillUpToDate() const;
 
     int block_size() const { return zita_config_.fragm; }
+    int run_ahead() const { return run_depth_; }         // this processor's run-ahead depth in blocks
     fe_stream* stream() const { return stream_; }      // for batched submission
     fe_engine* engine() const { return zita_config_.engine; }
     int device() const;
     bool ok() const { return ok_; }                     // false after an engine failure
 
 private:
-    SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream);
+    // A run-ahead chunk: up to run_depth_ consecutive whole blocks, read from the source in one go and
+    // computed by one engine request.
+    struct Chunk {
+        float* in = nullptr;            // page-locked, bound to the stream
+        float* out = nullptr;           // == in when ninp == nout
+        int blocks = 0;                 // whole blocks it holds
+        int next = 0;                   // next block to hand out
+        void* request = nullptr;        // BatchScheduler::Request while on the GPU
+    };
+    SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth);
     void Process();
+    bool ReadChunk(FrameSource* in, Chunk* c);    // true if the chunk holds at least one whole block
+    void SubmitChunk(Chunk* c);
+    void SettleChunk(Chunk* c);                   // wait for its request; on failure: silence, ok_ = false
+    void DrainRing();
+    void ScanPeaks(const float* v, size_t n);
 
     const ZitaConfig zita_config_;
     const std::string config_file_;
     const time_t config_file_timestamp_;
     fe_stream* const stream_;
 
+    const int run_depth_;               // 1: no run-ahead
     const size_t buffer_floats_;
+    const size_t arena_floats_;         // block buffer + both chunks, one page-locked allocation
     bool buffer_pinned_;
     float* const buffer_;
+    Chunk chunks_[2];
+    Chunk* cur_;                        // chunk blocks are handed out from (settled), or NULL
+    Chunk* ahead_;                      // chunk on the GPU, or NULL
+    const float* ring_block_;           // the current block's output inside cur_, NULL: the block buffer
+    float* tail_;                       // frames read ahead that do not fill a block (the file's short last block)
+    int tail_frames_;
+    bool source_short_;                 // the last read-ahead came back short: no more reads until the ring is empty
+    int depth_next_;                    // blocks the next chunk asks for (ramp)
     int input_pos_;
     int output_pos_;   // written position. -1, if not processed yet.
     float max_out_value_observed_;

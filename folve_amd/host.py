@@ -12,6 +12,7 @@ HOST_SYMBOLS = [
     ("fh_processor_create", _vp, [C.c_char_p, _i, _i]),
     ("fh_processor_destroy", None, [_vp]),
     ("fh_processor_fill_buffer", _i, [_vp, _vp, _i]),
+    ("fh_processor_fill_buffer2", _i, [_vp, _vp, _i, _pi]),
     ("fh_processor_write_processed", None, [_vp, _vp, _i]),
     ("fh_processor_is_input_buffer_complete", _i, [_vp]),
     ("fh_processor_pending_writes", _i, [_vp]),
@@ -39,6 +40,14 @@ HOST_SYMBOLS = [
     ("fh_batching_enabled", _i, []),
     ("fh_batcher_process", _i, [_vp, _vp, _vp, _i, _vp]),
     ("fh_batching_stats", None, [C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
+    ("fh_batching_stats2", None, [C.POINTER(_ll)] * 5),
+    ("fh_run_ahead_set", None, [_i]),
+    ("fh_run_ahead_get", _i, []),
+    ("fh_processor_run_ahead", _i, [_vp]),
+    ("fh_processor_fill_buffer_from", _i, [_vp, _vp, _vp]),
+    ("fh_processor_write_processed_to", None, [_vp, _vp, _vp, _i]),
+    ("fh_numa_placement_set", None, [_i]),
+    ("fh_pin_thread_near_device", _i, [_i]),
     ("fh_router_device_count", _i, []),
     ("fh_router_live_streams", _i, [_i]),
 ]
@@ -90,6 +99,7 @@ class SoundProcessor:
         self.ninp = L.fh_processor_input_channels(handle)
         self.nout = L.fh_processor_output_channels(handle)
         self.fragm = L.fh_processor_block_size(handle)
+        self._ahead = 0        # frames the processor has read beyond the ones it returned (run-ahead)
 
     @classmethod
     def create(cls, config_file, samplerate, channels):
@@ -97,13 +107,24 @@ class SoundProcessor:
         return cls(h) if h else None
 
     def fill_buffer(self, src):
+        """FillBuffer over an array span.  The reference reads from a file with a position (SNDFILE*); callers here
+        pass `x[done:]` with `done` advanced by the return value.  With run-ahead on the processor reads ahead of
+        what it returns, so this wrapper keeps the file position: the span handed to the C++ side starts where
+        the last read ended."""
         src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, self.ninp)
-        return _L().fh_processor_fill_buffer(self.h, src.ctypes.data_as(C.c_void_p), src.shape[0])
+        span = src[self._ahead:]
+        taken = C.c_int(0)
+        r = _L().fh_processor_fill_buffer2(self.h, span.ctypes.data_as(C.c_void_p), span.shape[0], C.byref(taken))
+        self._ahead += taken.value - r
+        return r
 
     def write_processed(self, count):
         out = np.zeros((count, self.nout), np.float32)
         _L().fh_processor_write_processed(self.h, out.ctypes.data_as(C.c_void_p), count)
         return out
+
+    def run_ahead(self):
+        return _L().fh_processor_run_ahead(self.h)
 
     def pending_writes(self):
         return _L().fh_processor_pending_writes(self.h)
@@ -122,6 +143,7 @@ class SoundProcessor:
 
     def reset(self):
         _L().fh_processor_reset(self.h)
+        self._ahead = 0
 
     def config_file(self):
         return os.fsdecode(_L().fh_processor_config_file(self.h))
@@ -198,6 +220,15 @@ def set_batching(enabled, window_us=-1, max_batch=-1):
 
 
 def batching_stats():
-    r, b, l = C.c_longlong(), C.c_longlong(), C.c_longlong()
-    _L().fh_batching_stats(C.byref(r), C.byref(b), C.byref(l))
-    return {"requests": r.value, "batches": b.value, "largest": l.value}
+    v = [C.c_longlong() for _ in range(5)]
+    _L().fh_batching_stats2(*[C.byref(x) for x in v])
+    return dict(zip(("requests", "blocks", "batches", "largest", "overlapped"), [x.value for x in v]))
+
+
+def set_run_ahead(blocks):
+    """Run-ahead depth (blocks) of SoundProcessors created from now on; 1 = off (folve::SoundProcessor::SetRunAhead)."""
+    _L().fh_run_ahead_set(int(blocks))
+
+
+def run_ahead():
+    return _L().fh_run_ahead_get()

@@ -66,6 +66,10 @@ int fe_engine_create(int device, void *hip_stream, fe_engine **out);
 void fe_engine_destroy(fe_engine *e);
 int fe_engine_synchronize(fe_engine *e);
 int fe_engine_device(const fe_engine *e);
+/* The host CPUs next to HIP device `device` as the kernel lists them ("0-31,128-159": sysfs local_cpulist of the
+ * device's PCI function), for hosts that place file threads and page-locked buffers on the GPU's NUMA node.
+ * FE_ERR_UNSUPPORTED if the system does not say. */
+int fe_device_local_cpulist(int device, char *buf, size_t size);
 const char *fe_last_error(void);      /* thread-local detail of the last failure */
 
 /* ---- filter: replaces Convproc::configure / impdata_create / impdata_copy - */
@@ -130,6 +134,8 @@ int fe_stream_process_blocks(fe_stream *s, const float *in, long long nframes, f
 int fe_stream_get_peaks(fe_stream *s, float *peak_signed, float *peak_abs);
 int fe_stream_reset_peaks(fe_stream *s);
 long long fe_stream_blocks_done(const fe_stream *s);
+int fe_stream_block_size(const fe_stream *s);     /* P of the stream's filter */
+int fe_stream_max_blocks(const fe_stream *s);     /* the max_blocks_per_call it was opened with */
 
 /* ---- batch: many independent streams in one launch ------------------------ */
 /* streams[i] consumes nframes[i] interleaved frames from in[i] and produces as
@@ -144,12 +150,17 @@ int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, c
  * (fe_stream_bind_host_buffer; otherwise FE_ERR_UNSUPPORTED and nothing is enqueued): submit enqueues the
  * kernels and returns at once with a ticket; fe_ticket_wait returns when the outputs are in the callers'
  * buffers, and consumes the ticket.  A host can keep one batch running while it assembles and submits the
- * next (folve_amd/csrc/host/batch_scheduler.cpp does): batches execute in submission order.  A stream may
- * be in one submitted batch at a time, and a ticket must be waited for before its streams are closed. */
+ * next (folve_amd/csrc/host/batch_scheduler.cpp does).  Submitted batches go to one of two launch lanes (HIP
+ * streams) and may overlap on the GPU; the calls of any ONE stream execute in the order they were made,
+ * whichever lane they land on.  A stream may be in one submitted batch at a time, and a ticket must be
+ * waited for before its streams are closed, reset or used in a synchronous call. */
 typedef struct fe_ticket fe_ticket;
 int fe_batch_submit(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
                     float *const *out, fe_ticket **ticket);
 int fe_ticket_wait(fe_ticket *ticket);
+/* 1 if fe_ticket_wait would return without waiting, 0 if the batch is still on the GPU, negative on a device
+ * error; does not consume the ticket. */
+int fe_ticket_done(fe_ticket *ticket);
 
 /* Running peaks of n streams with one synchronisation (what the batcher hands back per block). */
 int fe_batch_get_peaks(fe_stream *const *streams, int n, float *peak_signed, float *peak_abs);
@@ -164,7 +175,10 @@ enum {
     FE_TUNE_INV_RUN = 1,   /* K3 walker: consecutive blocks per workgroup */
     FE_TUNE_MAC_FORM = 2,  /* K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk */
     FE_TUNE_FFT_FORM = 3,  /* K1/K3: 1 general kernels only, 2 walkers whenever the shape allows */
-    FE_TUNE_FAIL_NEXT = 4  /* fault injection: the n-th launch round of this engine from now fails with FE_ERR_DEVICE (1 = the next) */
+    FE_TUNE_FAIL_NEXT = 4, /* fault injection: the n-th launch round of this engine from now fails with FE_ERR_DEVICE (1 = the next;
+                              negative: every round until the knob is set to 0) */
+    FE_TUNE_LANES = 5      /* fe_batch_submit: 1 = every batch on the engine's own HIP stream, 0 / 2 = two lanes (batches of different
+                              streams overlap: one reads its PCM over the bus while the other writes its results back) */
 };
 int fe_engine_set_tuning(fe_engine *e, int knob, int value);
 /* Device self-test of the cross-lane exchange the FFT rows use (kernels.h launch_xlane_selftest). */

@@ -34,8 +34,24 @@ fh_processor *fh_processor_create(const char *config_file, int samplerate, int c
 void fh_processor_destroy(fh_processor *p);
 /* FillBuffer (cc:76): reads min(frames_available, block - input_pos) frames from src; returns frames taken */
 int fh_processor_fill_buffer(fh_processor *p, const float *src, int frames_available);
+/* The same, also telling how many frames of `src` the processor took: with run-ahead on it reads AHEAD of the
+ * frames it returns (the source is a file with a position, as SNDFILE* is), so a caller that passes spans of one
+ * array must start the next span `*consumed` frames further, not `return value` frames (folve_amd/host.py does). */
+int fh_processor_fill_buffer2(fh_processor *p, const float *src, int frames_available, int *consumed);
 /* WriteProcessed (cc:86): processes if needed, copies sample_count frames to dst */
 void fh_processor_write_processed(fh_processor *p, float *dst, int sample_count);
+/* The same two calls over callbacks with libsndfile's contract — read(user, dst, frames) as sf_readf_float,
+ * write(user, src, frames) as sf_writef_float — for hosts whose "file" is longer than one span: with run-ahead
+ * on, FillBuffer asks the source for many blocks at once (sound_processor.h). */
+typedef int (*fh_read_fn)(void *user, float *dst, int frames);
+typedef int (*fh_write_fn)(void *user, const float *src, int frames);
+int fh_processor_fill_buffer_from(fh_processor *p, fh_read_fn read, void *user);
+void fh_processor_write_processed_to(fh_processor *p, fh_write_fn write, void *user, int sample_count);
+/* Run-ahead depth in blocks for processors created from now on (1 = off; default 32 or FOLVE_AMD_RUN_AHEAD);
+ * fh_processor_run_ahead: the depth a given processor was created with. */
+void fh_run_ahead_set(int blocks);
+int fh_run_ahead_get(void);
+int fh_processor_run_ahead(const fh_processor *p);
 int fh_processor_is_input_buffer_complete(const fh_processor *p);
 int fh_processor_pending_writes(const fh_processor *p);
 int fh_processor_input_channels(const fh_processor *p);
@@ -72,6 +88,14 @@ int fh_batching_enabled(void);
 int fh_batcher_process(fe_engine *engine, fe_stream *s, const float *in, int valid_frames, float *out);
 /* totals over all GPUs since process start */
 void fh_batching_stats(long long *requests, long long *batches, long long *largest);
+/* the same plus: blocks carried by the requests, and batches submitted while another was still on the GPU */
+void fh_batching_stats2(long long *requests, long long *blocks, long long *batches, long long *largest, long long *overlapped);
+
+/* NUMA placement (folve_amd/csrc/host/numa_placement.h): with it on, a processor's page-locked ring is allocated
+ * next to the GPU the router picked; fh_pin_thread_near_device moves the calling thread there too (1 = moved).
+ * Off by default (FOLVE_AMD_NUMA=1 turns it on). */
+void fh_numa_placement_set(int on);
+int fh_pin_thread_near_device(int device);
 
 /* the process-wide GPU sharder */
 int fh_router_device_count(void);

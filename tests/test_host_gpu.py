@@ -182,9 +182,19 @@ def test_processors_run_concurrently_from_threads(oracle, tmp_path):
     assert H._L().fh_router_live_streams(0) >= len(sigs)
 
 
-def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
+def test_combiner_coalesces_one_block_calls_and_is_bit_identical(oracle, tmp_path):
     """folve::BatchScheduler: Process() calls of many file threads that meet on a busy GPU leave as one
-    launch; there is no timer — a lone call is never delayed (see the latency test)."""
+    launch; there is no timer — a lone call is never delayed (see the latency test).
+    Run-ahead off here: every request is the reference's one block per Process() call, and such requests use the
+    same kernel forms alone and combined (batches of at most 64 blocks), hence the same bits."""
+    H.set_run_ahead(1)
+    try:
+        _combiner_one_block_calls(oracle, tmp_path)
+    finally:
+        H.set_run_ahead(32)
+
+
+def _combiner_one_block_calls(oracle, tmp_path):
     d, hs = make_santalucia_shaped_dir(tmp_path)
     conf = os.path.join(d, "filter-44100.conf")
     sigs = [seeded_input(70 + i, 5 * 8192 + 64 * i, 2) for i in range(12)]
@@ -207,7 +217,7 @@ def test_run_ahead_batcher_coalesces_and_is_bit_identical(oracle, tmp_path):
     after = H.batching_stats()
     nreq = after["requests"] - before["requests"]
     nbat = after["batches"] - before["batches"]
-    assert nreq == sum((len(x) + 8191) // 8192 for x in sigs)
+    assert nreq == sum((len(x) + 8191) // 8192 for x in sigs) == after["blocks"] - before["blocks"]
     assert nbat < nreq and after["largest"] >= 2                 # blocks of different files shared launches
     for a, b in zip(plain, batched):
         assert np.array_equal(a, b)                                # same kernels, same per-stream arithmetic
@@ -336,8 +346,9 @@ def test_failed_processor_is_not_pooled(oracle, tmp_path):
     L.fh_processor_engine.restype = C.c_void_p
     L.fh_processor_engine.argtypes = [C.c_void_p]
     eng = L.fh_processor_engine(bad.h)
-    assert L.fe_engine_set_tuning(C.c_void_p(eng), 4, 1) == 0       # FE_TUNE_FAIL_NEXT
-    z = bad.run(x)                                                   # the block fails on the "device"
+    assert L.fe_engine_set_tuning(C.c_void_p(eng), 4, -1) == 0      # FE_TUNE_FAIL_NEXT: every launch round fails (a dead device:
+    z = bad.run(x)                                                   #   the combiner's block-by-block retry fails too)
+    assert L.fe_engine_set_tuning(C.c_void_p(eng), 4, 0) == 0
     assert not z.any() and L.fh_processor_ok(bad.h) == 0             # zeros out, as documented
     pool.give_back(bad)
     assert pool.pooled_count(conf) == 0                              # discarded, not pooled

@@ -1,8 +1,12 @@
 // The drop-in call pattern under load: N "file" threads, each with its own folve::SoundProcessor (through the C view of
 // the host classes, include/folve_host.h), each pulling 8192-frame blocks the way ConvolveFileHandler does
 // (/root/reference/convolve-file-handler.cc:335-347,370-424): FillBuffer -> WriteProcessed (which runs Process()).
-// Prints blocks per second over all threads, the latency of a block as a thread sees it, and what the per-GPU
-// combiner made of the calls.   usage: dropin_threads <filter.conf> <threads> <blocks per thread> <batching 0|1> [json]
+// A thread's "file" is `blocks` blocks long; its source is a callback with sf_readf_float's contract over a cyclic
+// buffer of seeded noise, its sink a callback with sf_writef_float's that copies the block out — so that a processor
+// with run-ahead on can ask for many blocks at once, exactly as it would ask libsndfile.
+// Prints blocks per second over all threads and per GPU, the latency of a block as a thread sees it, and what the
+// per-GPU combiner made of the calls.
+//   usage: dropin_threads <filter.conf> <threads> <blocks per thread> <batching 0|1> [json] [run_ahead=N] [file_blocks=N] [pin=0|1]
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -10,6 +14,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
 #include <random>
 #include <string>
 #include <thread>
@@ -17,11 +23,51 @@
 
 #include "folve_host.h"
 
+namespace {
+struct File {                      // what a thread reads from and writes to
+    std::vector<float> data;       // cyclic source, `cycle` frames
+    std::vector<float> sink;       // one block
+    long long left = 0;            // frames until end of file
+    size_t pos = 0;                // frame position inside the cycle
+    size_t cycle = 0;
+    int cin = 0, cout = 0;
+};
+int read_cb(void* user, float* dst, int frames) {
+    File* f = static_cast<File*>(user);
+    const int n = (int)std::min<long long>(frames, f->left);
+    int done = 0;
+    while (done < n) {
+        const int run = (int)std::min<size_t>((size_t)(n - done), f->cycle - f->pos);
+        memcpy(dst + (size_t)done * f->cin, f->data.data() + f->pos * f->cin, sizeof(float) * (size_t)run * f->cin);
+        f->pos = (f->pos + (size_t)run) % f->cycle;
+        done += run;
+    }
+    f->left -= n;
+    return n;
+}
+int write_cb(void* user, const float* src, int frames) {
+    File* f = static_cast<File*>(user);
+    memcpy(f->sink.data(), src, sizeof(float) * (size_t)frames * f->cout);
+    return frames;
+}
+}  // namespace
+
 int main(int argc, char** argv) {
-    if (argc < 5) { fprintf(stderr, "usage: %s conf threads blocks batching\n", argv[0]); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: %s conf threads blocks batching [json] [run_ahead=N] [file_blocks=N] [pin=0|1]\n", argv[0]); return 2; }
     const char* conf = argv[1];
     const int nthreads = atoi(argv[2]), nblocks = atoi(argv[3]), batching = atoi(argv[4]);
-    fh_batching_set(batching, 0, 64);
+    bool json = false;
+    int run_ahead = 1, file_blocks = 64, pin = 0;
+    for (int i = 5; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "json") json = true;
+        else if (a.rfind("run_ahead=", 0) == 0) run_ahead = atoi(a.c_str() + 10);
+        else if (a.rfind("file_blocks=", 0) == 0) file_blocks = atoi(a.c_str() + 12);
+        else if (a.rfind("pin=", 0) == 0) pin = atoi(a.c_str() + 4);
+    }
+    fh_batching_set(batching, 0, 256);
+    fh_run_ahead_set(run_ahead);
+    fh_numa_placement_set(pin);
     std::vector<fh_processor*> procs;
     for (int i = 0; i < nthreads; ++i) {
         fh_processor* p = fh_processor_create(conf, 44100, 2);
@@ -30,59 +76,79 @@ int main(int argc, char** argv) {
     }
     const int P = fh_processor_block_size(procs[0]);
     const int cin = fh_processor_input_channels(procs[0]), cout = fh_processor_output_channels(procs[0]);
+    const int warm = std::max(8, 3 * run_ahead);                 // past the run-ahead ramp, clocks up
     std::atomic<int> ready{0};
     std::atomic<bool> go{false};
     std::vector<std::vector<float>> lat((size_t)nthreads);
     std::vector<std::thread> th;
-    long long r0, b0, l0;
-    fh_batching_stats(&r0, &b0, &l0);
+    long long r0, k0, b0, l0, o0;
     for (int t = 0; t < nthreads; ++t) {
         th.emplace_back([&, t] {
+            fh_processor* p = procs[(size_t)t];
+            if (pin) fh_pin_thread_near_device(fh_processor_device(p));
             std::mt19937 rng(100 + t);
             std::uniform_real_distribution<float> u(-1.f, 1.f);
-            std::vector<float> src((size_t)P * cin), dst((size_t)P * cout);
-            for (auto& v : src) v = u(rng);
-            fh_processor* p = procs[(size_t)t];
-            for (int w = 0; w < 8; ++w) {                     // warm: first launches, clocks
-                fh_processor_fill_buffer(p, src.data(), P);
-                fh_processor_write_processed(p, dst.data(), P);
-            }
+            File f;
+            f.cin = cin; f.cout = cout;
+            f.cycle = (size_t)std::max(1, std::min(file_blocks, nblocks)) * P;
+            f.data.resize(f.cycle * cin);
+            f.sink.resize((size_t)P * cout);
+            for (auto& v : f.data) v = u(rng);
+            auto pull = [&](int blocks, std::vector<float>* lats) {       // AddMoreSoundData until the file ends
+                f.left = (long long)blocks * P;
+                long long todo = f.left;
+                while (todo > 0) {
+                    const auto a = std::chrono::steady_clock::now();
+                    const int r = fh_processor_fill_buffer_from(p, read_cb, &f);
+                    if (r <= 0) break;
+                    fh_processor_write_processed_to(p, write_cb, &f, r);
+                    todo -= r;
+                    if (lats) lats->push_back(std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count());
+                }
+            };
+            pull(warm, nullptr);
             lat[(size_t)t].reserve((size_t)nblocks);
             ready.fetch_add(1);
             while (!go.load()) std::this_thread::yield();
-            for (int b = 0; b < nblocks; ++b) {
-                const auto a = std::chrono::steady_clock::now();
-                fh_processor_fill_buffer(p, src.data(), P);
-                fh_processor_write_processed(p, dst.data(), P);
-                lat[(size_t)t].push_back(std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count());
-            }
+            pull(nblocks, &lat[(size_t)t]);
         });
     }
     while (ready.load() < nthreads) std::this_thread::yield();
+    fh_batching_stats2(&r0, &k0, &b0, &l0, &o0);
     const auto t0 = std::chrono::steady_clock::now();
     go.store(true);
     for (auto& x : th) x.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    long long r1, b1, l1;
-    fh_batching_stats(&r1, &b1, &l1);
+    long long r1, k1, b1, l1, o1;
+    fh_batching_stats2(&r1, &k1, &b1, &l1, &o1);
     std::vector<float> all;
     for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
     std::sort(all.begin(), all.end());
     const double blocks = (double)nthreads * nblocks;
     int ok = 1;
-    for (auto* p : procs) ok &= fh_processor_ok(p);
-    if (argc > 5 && std::string(argv[5]) == "json") {
-        printf("{\"threads\": %d, \"combiner\": %s, \"blocks_per_s\": %.0f, \"msamples_per_s\": %.1f, \"block_latency_us_median\": %.1f, "
-               "\"block_latency_us_p99\": %.1f, \"engine_calls\": %lld, \"largest_batch\": %lld, \"ok\": %s}\n",
-               nthreads, batching ? "true" : "false", blocks / dt, blocks * P * cout / dt / 1e6, all[all.size() / 2], all[all.size() * 99 / 100],
-               b1 - b0, l1, ok ? "true" : "false");
+    std::map<int, int> per_gpu;
+    for (auto* p : procs) { ok &= fh_processor_ok(p); per_gpu[fh_processor_device(p)]++; }
+    std::string gpus = "{";
+    for (auto& kv : per_gpu) {
+        char b[128];
+        snprintf(b, sizeof(b), "%s\"%d\": {\"streams\": %d, \"blocks_per_s\": %.0f}", gpus.size() > 1 ? ", " : "", kv.first, kv.second,
+                 (double)kv.second * nblocks / dt);
+        gpus += b;
+    }
+    gpus += "}";
+    if (json) {
+        printf("{\"threads\": %d, \"combiner\": %s, \"run_ahead\": %d, \"blocks_per_s\": %.0f, \"msamples_per_s\": %.1f, \"block_latency_us_median\": %.1f, "
+               "\"block_latency_us_p99\": %.1f, \"requests\": %lld, \"engine_calls\": %lld, \"largest_batch_blocks\": %lld, \"overlapped_batches\": %lld, "
+               "\"gpus\": %s, \"numa_pin\": %s, \"ok\": %s}\n",
+               nthreads, batching ? "true" : "false", run_ahead, blocks / dt, blocks * P * cout / dt / 1e6, all[all.size() / 2], all[all.size() * 99 / 100],
+               r1 - r0, b1 - b0, l1, o1 - o0, gpus.c_str(), pin ? "true" : "false", ok ? "true" : "false");
         for (auto* p : procs) fh_processor_destroy(p);
         return ok ? 0 : 1;
     }
-    printf("threads %3d batching %d: %9.0f blocks/s = %7.1f Msamples/s (%d ch), block latency median %6.1f us, p99 %7.1f us; "
-           "combiner: %lld calls in %lld launches (largest %lld); ok %d\n",
-           nthreads, batching, blocks / dt, blocks * P * cout / dt / 1e6, cout, all[all.size() / 2], all[all.size() * 99 / 100],
-           r1 - r0, b1 - b0, l1, ok);
+    printf("threads %3d batching %d run-ahead %3d: %9.0f blocks/s = %7.1f Msamples/s (%d ch), block latency median %6.1f us, p99 %7.1f us; "
+           "combiner: %lld requests (%lld blocks) in %lld launches (largest %lld blocks, %lld overlapped); gpus %s; ok %d\n",
+           nthreads, batching, run_ahead, blocks / dt, blocks * P * cout / dt / 1e6, cout, all[all.size() / 2], all[all.size() * 99 / 100],
+           r1 - r0, k1 - k0, b1 - b0, l1, o1 - o0, gpus.c_str(), ok);
     // with the TRACE build of the library (make -C folve_amd/csrc TRACE=1; LD_LIBRARY_PATH / rpath to it): where the
     // host's time between two engine calls goes
     typedef int (*host_times_fn)(unsigned long long*, int);
