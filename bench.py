@@ -537,7 +537,7 @@ def main():
                     f.write("/impulse/read %d %d 2e-3 0 0 0 %d ir.wav\n" % (c + 1, c + 1, c + 1))
             runs = []
             # (threads, combiner, run-ahead depth in blocks): depth 1 is the reference's one block per Process() call
-            for nt, comb, ra in ((1, 1, 1), (1, 1, 32), (16, 1, 32), (64, 1, 1), (64, 1, 32), (64, 1, 128), (64, 0, 1)):
+            for nt, comb, ra in ((1, 1, 1), (1, 1, 32), (16, 1, 32), (64, 1, 1), (64, 1, 32), (64, 1, 64), (64, 0, 1)):
                 nblk = 300 if ra == 1 else (20000 if nt == 1 else 4096 if nt <= 16 else 2048)
                 r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), str(nblk), str(comb), "json",
                                     "run_ahead=%d" % ra],

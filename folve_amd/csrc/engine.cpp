@@ -89,6 +89,12 @@ struct fe_engine {
     int lane_toggle = 0;
     fk::Tuning tuning;                   // launch-shape overrides (fe_engine_set_tuning)
     bool host_io = false;                // the call in progress runs zero-copy on page-locked host buffers
+    bool in_resident = false;            // ... its input has been staged into device memory by DMA (run_duplex)
+    float* dx_stage[2] = {};             // run_duplex: input staging, alternating between consecutive batches
+    size_t dx_stage_bytes[2] = {};
+    hipEvent_t dx_free[2] = {};          // the batch that last used dx_stage[i] has finished
+    bool dx_free_pending[2] = {};
+    int dx_parity = 0;
     // rotating pinned/device buffers for job descriptors (async uploads)
     fk::StreamJob* jobs_host[kJobSlots] = {};
     fk::StreamJob* jobs_dev[kJobSlots] = {};
@@ -107,6 +113,7 @@ struct fe_engine {
     hipStream_t cp_in = nullptr, cp_out = nullptr;
     hipEvent_t ev_in[kMaxChunks] = {}, ev_k[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ticket_events;   // idle completion events of fe_batch_submit tickets
+    hipEvent_t dx_ev[16] = {};               // run_duplex: "K1 of chunk c has finished"
     // profiling
     int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none, < 0: every round)
     bool tuning_single_lane = false;     // FE_TUNE_LANES = 1: every submitted batch on lane 0 (measurements)
@@ -119,8 +126,8 @@ struct fe_engine {
 struct fe_ticket {                  // a submitted batch whose outputs are not yet known to be in the caller's buffers
     fe_engine* e = nullptr;          // (holds a reference)
     hipEvent_t ev = nullptr;
-    int lane = 0;
-    long long seq = 0;               // the lane's sequence number of this batch
+    int lane = 0;                    // the lane its completion event is recorded on
+    long long seq[2] = {0, 0};       // per lane: the sequence number of this batch there (0: lane not used)
 };
 
 struct PathHost {
@@ -221,7 +228,7 @@ struct Item {
 // One launch round over streams that share a filter.  Host-side stream state (ring position, block
 // count) advances only after all three launches were accepted: a failed round leaves every stream
 // where it was.
-int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane) {
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane, hipEvent_t after_k1 = nullptr) {
     Lane& L = e->lanes[lane];
     hipStream_t st = L.st;
     const int P = f->P;
@@ -296,9 +303,11 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     }
     fk::Tuning tn = e->tuning;
     tn.host_io = e->host_io;
+    tn.in_resident = e->in_resident;
     tn.one_job = (nj == 1 && dj == e->jobs_host[slot]) ? e->jobs_host[slot] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
+    if (after_k1) HIP_TRY(hipEventRecord(after_k1, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
     HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, L.Y, max_blocks, f->mac_shape, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
@@ -331,7 +340,8 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
 
 // Launch rounds for streams [i0, i1) of a call, grouped by filter; each group runs until its
 // frames are consumed.
-int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int i0, int i1, int lane = 0) {
+int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int i0, int i1, int lane = 0,
+               hipEvent_t after_k1 = nullptr) {
     std::vector<char> done((size_t)(i1 - i0), 0);
     for (int i = i0; i < i1; ++i) {
         if (done[(size_t)(i - i0)]) continue;
@@ -341,7 +351,7 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
             if (!done[(size_t)(k - i0)] && streams[k]->f == f) { group.push_back(all[(size_t)k]); done[(size_t)(k - i0)] = 1; }
         bool any = true, enqueued = i > i0;
         while (any) {
-            int rc = launch_round(e, f, group, &any, lane);
+            int rc = launch_round(e, f, group, &any, lane, after_k1);
             if (rc) {
                 // Kernels of earlier rounds of this call are already on the GPU and still write into the
                 // callers' buffers: the error is reported only after they have drained, so that a caller
@@ -359,8 +369,8 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
 // all[i].in / .out already point into the staging buffers.
 int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* const* in, float* const* out,
                   const long long* nframes, std::vector<Item>& all) {
-    if (!e->cp_in) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->cp_in, hipStreamNonBlocking));
+    if (!e->cp_out) {
+        if (!e->cp_in) HIP_TRY(hipStreamCreateWithFlags(&e->cp_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&e->cp_out, hipStreamNonBlocking));
         for (int i = 0; i < kMaxChunks; ++i) {
             HIP_TRY(hipEventCreateWithFlags(&e->ev_in[i], hipEventDisableTiming));
@@ -420,6 +430,94 @@ int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* c
     return FE_OK;
 }
 
+// A large zero-copy call (the combined run-ahead chunks of many files: tens of megabytes of PCM each way) as a
+// duplex pipeline.  Measured on MI355X (profiles/r03_dropin_*): kernels WRITE page-locked host memory at 43 - 50 GB/s,
+// but READ it at 28 - 35 GB/s only (64-byte read requests, a bounded number in flight), where the DMA engines read at
+// the bus rate.  So the streams are cut into chunks; every chunk's PCM is copied into device memory by the copy
+// stream (inbound, DMA), its K1/K2 run from HBM and its K3 writes the results straight into the callers' buffers
+// (outbound, kernel stores).  Chunks alternate between the two lanes, so the K3 of chunk c runs beside the K1/K2 of
+// chunk c + 1 and beside the copies of the chunks after it: both directions of the bus are busy for the whole call,
+// whatever the host threads' timing is.  The staging buffer alternates between consecutive batches, so the next
+// batch's copies start while this one still computes.  At the end `lane` (the one the caller records its completion
+// event on) waits for the other.
+constexpr int kDuplexChunks = 16;
+struct DuplexPlan {
+    int nc = 0;
+    int first[kDuplexChunks + 1] = {};
+};
+// chunk boundaries: whole streams, about equal byte counts; lane_of[i] = the lane stream i's chunk runs on
+void plan_duplex(fe_stream* const* streams, int n, const long long* nframes, int lane, int chunks, DuplexPlan* p, int* lane_of) {
+    long long total = 0;
+    for (int i = 0; i < n; ++i) total += nframes[i] * (streams[i]->f->ninp + streams[i]->f->nout);
+    long long acc = 0;
+    p->nc = 0;
+    p->first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        acc += nframes[i] * (streams[i]->f->ninp + streams[i]->f->nout);
+        lane_of[i] = (lane + p->nc) & 1;
+        if (p->nc + 1 < chunks && acc * chunks >= total * (p->nc + 1) && i + 1 < n) p->first[++p->nc] = i + 1;
+    }
+    p->first[++p->nc] = n;
+}
+int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int n, const float* const* host_in,
+               const long long* nframes, int lane, const DuplexPlan& p) {
+    if (!e->dx_ev[0]) {
+        for (int i = 0; i < kDuplexChunks; ++i) HIP_TRY(hipEventCreateWithFlags(&e->dx_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&e->dx_free[i], hipEventDisableTiming));
+    }
+    if (!e->cp_in) HIP_TRY(hipStreamCreateWithFlags(&e->cp_in, hipStreamNonBlocking));
+    const int par = e->dx_parity;
+    e->dx_parity ^= 1;
+    // the batch before last used this staging buffer: it has long finished (at most two batches are in flight)
+    if (e->dx_free_pending[par]) {
+        HIP_TRY(hipEventSynchronize(e->dx_free[par]));
+        e->dx_free_pending[par] = false;
+    }
+    size_t need = 0;
+    std::vector<size_t> off((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        off[(size_t)i] = need;
+        need += (((size_t)nframes[i] * streams[i]->f->ninp + 3) & ~(size_t)3) * sizeof(float);
+    }
+    if (e->dx_stage_bytes[par] < need) {
+        if (e->dx_stage[par]) HIP_TRY(hipFree(e->dx_stage[par]));
+        e->dx_stage[par] = nullptr;
+        e->dx_stage_bytes[par] = 0;
+        HIP_TRY(hipMalloc((void**)&e->dx_stage[par], need + need / 4));
+        e->dx_stage_bytes[par] = need + need / 4;
+    }
+    struct ResidentScope {
+        fe_engine* e;
+        explicit ResidentScope(fe_engine* e_) : e(e_) { e->in_resident = true; }
+        ~ResidentScope() { e->in_resident = false; }
+    } resident(e);
+    const int nc = p.nc;
+    const int* first = p.first;
+    for (int c = 0; c < nc; ++c) {
+        const int l = (lane + c) & 1;
+        for (int i = first[c]; i < first[c + 1]; ++i) {
+            const size_t bytes = (size_t)nframes[i] * streams[i]->f->ninp * sizeof(float);
+            float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(e->dx_stage[par]) + off[(size_t)i]);
+            if (bytes) HIP_TRY(hipMemcpyAsync(dst, host_in[i], bytes, hipMemcpyHostToDevice, e->cp_in));
+            all[(size_t)i].in = dst;
+        }
+        HIP_TRY(hipEventRecord(e->dx_ev[c], e->cp_in));
+        HIP_TRY(hipStreamWaitEvent(e->lanes[l].st, e->dx_ev[c], 0));
+        int rc = run_groups(e, streams, all, first[c], first[c + 1], l);
+        if (rc) {
+            (void)hipStreamSynchronize(e->lanes[l ^ 1].st);     // earlier chunks still write into the callers' buffers
+            (void)hipStreamSynchronize(e->cp_in);
+            return rc;
+        }
+    }
+    const int other = lane ^ 1;
+    HIP_TRY(hipEventRecord(e->lanes[other].xev, e->lanes[other].st));
+    HIP_TRY(hipStreamWaitEvent(e->lanes[lane].st, e->lanes[other].xev, 0));
+    HIP_TRY(hipEventRecord(e->dx_free[par], e->lanes[lane].st));
+    e->dx_free_pending[par] = true;
+    return FE_OK;
+}
+
 #ifdef FOLVE_PHASE_TRACE
 // TRACE build only: where the host's share of the one-block call goes (ns, summed; tools/phase_trace_single.py)
 static unsigned long long g_host_ns[8];     // [0] entry -> launches enqueued, [1] -> completion seen, [2] calls, [3] polls, [4] exit -> next entry
@@ -452,6 +550,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     std::vector<const float*> zc_in;
     std::vector<float*> zc_out;
     bool zero_copy = false;
+    const float* const* host_in = in;    // the callers' own pointers (run_duplex copies from them)
     if (!device_ptrs && n > 0) {
         bool all_bound = true;
         for (int i = 0; i < n && all_bound; ++i) {
@@ -502,29 +601,42 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         in_floats += ((size_t)nframes[i] * s->f->ninp + 3) & ~(size_t)3;
         out_floats += ((size_t)nframes[i] * s->f->nout + 3) & ~(size_t)3;
     }
-    // A stream whose last call ran on the other lane and is not known to have completed: this lane waits
-    // (on the device) for everything that lane holds so far.  One wait per call covers all such streams.
+    // A big submitted zero-copy batch runs as a duplex pipeline over both lanes (run_duplex).
+    std::vector<int> lane_of((size_t)n, lane);
+    DuplexPlan dplan;
+    const size_t io_bytes = (in_floats + out_floats) * sizeof(float);
+    const bool duplex = submit_event && zero_copy && !e->tuning_single_lane && !e->profiling && e->lanes[1].st && n >= 2 &&
+                        io_bytes >= ((size_t)32 << 20);
+    if (duplex) {
+        const int chunks = (int)std::max<size_t>(2, std::min<size_t>({(size_t)kDuplexChunks, (size_t)n, io_bytes / ((size_t)32 << 20) + 1}));
+        plan_duplex(streams, n, nframes, lane, chunks, &dplan, lane_of.data());
+    }
+    // A stream whose last call ran on another lane and is not known to have completed: its lane of this call
+    // waits (on the device) for everything that lane holds so far.  One wait per pair of lanes covers all such streams.
     {
-        bool waited[kLanes] = {};
+        bool waited[kLanes][kLanes] = {};
         for (int i = 0; i < n; ++i) {
             const fe_stream* s = streams[i];
-            const int ol = s->last_lane;
-            if (ol < 0 || ol == lane || waited[ol] || s->last_seq <= e->lanes[ol].done) continue;
+            const int ol = s->last_lane, nl = lane_of[(size_t)i];
+            if (ol < 0 || ol == nl || waited[nl][ol] || s->last_seq <= e->lanes[ol].done) continue;
             HIP_TRY(hipEventRecord(e->lanes[ol].xev, e->lanes[ol].st));
-            HIP_TRY(hipStreamWaitEvent(st, e->lanes[ol].xev, 0));
-            waited[ol] = true;
+            HIP_TRY(hipStreamWaitEvent(e->lanes[nl].st, e->lanes[ol].xev, 0));
+            waited[nl][ol] = true;
         }
     }
     const long long seq = L.submitted + 1;
-    if (seq_out) *seq_out = seq;
-    // (whatever happens below, kernels of this call may have been enqueued: the streams belong to this lane now)
+    long long seqs[kLanes] = {0, 0};
+    seqs[lane] = seq;
+    if (duplex) seqs[lane ^ 1] = e->lanes[lane ^ 1].submitted + 1;
+    if (seq_out) { seq_out[0] = seqs[0]; seq_out[1] = seqs[1]; }
+    // (whatever happens below, kernels of this call may have been enqueued: the streams belong to their lanes now)
     struct LaneScope {
-        Lane& L; fe_stream* const* streams; int n; int lane; long long seq;
+        fe_engine* e; fe_stream* const* streams; int n; const int* lane_of; const long long* seqs;
         ~LaneScope() {
-            L.submitted = seq;
-            for (int i = 0; i < n; ++i) { streams[i]->last_lane = lane; streams[i]->last_seq = seq; }
+            for (int l = 0; l < kLanes; ++l) if (seqs[l]) e->lanes[l].submitted = seqs[l];
+            for (int i = 0; i < n; ++i) { streams[i]->last_lane = lane_of[i]; streams[i]->last_seq = seqs[lane_of[i]]; }
         }
-    } lane_scope{L, streams, n, lane, seq};
+    } lane_scope{e, streams, n, lane_of.data(), seqs};
     if (!device_ptrs) {
         int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
         if (rc) return rc;
@@ -553,7 +665,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
                 if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, st));
             }
         }
-        int rc = run_groups(e, streams, all, 0, n, lane);
+        int rc = duplex ? run_duplex(e, streams, all, n, host_in, nframes, lane, dplan) : run_groups(e, streams, all, 0, n, lane);
         if (rc) return rc;
         if (!device_ptrs) {
             for (int i = 0; i < n; ++i) {
@@ -702,6 +814,11 @@ static void engine_release(fe_engine* e) {
     for (int i = 0; i < kMaxChunks; ++i) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
         if (e->ev_k[i]) (void)hipEventDestroy(e->ev_k[i]);
+    }
+    for (hipEvent_t ev : e->dx_ev) if (ev) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; ++i) {
+        if (e->dx_free[i]) (void)hipEventDestroy(e->dx_free[i]);
+        if (e->dx_stage[i]) (void)hipFree(e->dx_stage[i]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -1155,7 +1272,7 @@ int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, co
         delete t;
         return fail(FE_ERR_DEVICE, "hipEventCreate failed");
     }
-    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev, lane, &t->seq);
+    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev, lane, t->seq);
     if (rc) {
         e->ticket_events.push_back(t->ev);      // (never recorded: nothing pends on it)
         delete t;
@@ -1204,7 +1321,8 @@ int fe_ticket_wait(fe_ticket* t) {
         Lane& L = e->lanes[t->lane];
         L.outstanding--;
         if (done) {
-            if (t->seq > L.done) L.done = t->seq;
+            for (int l = 0; l < kLanes; ++l)
+                if (t->seq[l] > e->lanes[l].done) e->lanes[l].done = t->seq[l];
             e->ticket_events.push_back(t->ev);
         } else {
             (void)hipEventDestroy(t->ev);        // may still be pending: never recycled

@@ -18,6 +18,10 @@ struct BatchScheduler::Request {
     std::string error;
     State state = kQueued;                  // under mu_
     std::shared_ptr<Batch> batch;           // once taken out of the queue
+    // Its thread sleeps here (in Wait) and is woken exactly when the request changes state: taken into a batch,
+    // batch submitted, batch complete.  The request lives until Wait returns, and notifiers hold mu_.
+    std::condition_variable cv;
+    bool sleeping = false;
 };
 
 namespace {
@@ -71,8 +75,9 @@ BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, l
     stats_.requests++;
     stats_.blocks += r->blocks;
     queue_.push_back(r);
-    if (lanes_busy_ >= kLanes && !pumping_) {
-        // Both lanes taken.  If one of the batches has finished unobserved (its threads are all busy serving
+    queued_blocks_ += r->blocks;
+    if (lanes_busy_ > 0 && !pumping_) {
+        // The GPU is taken.  If one of the batches has finished unobserved (its threads are all busy serving
         // what they got earlier), retire it now so that the queue — this request included — moves on.
         std::shared_ptr<Batch> finished;
         for (const std::shared_ptr<Batch>& b : flying_)
@@ -101,8 +106,13 @@ int BatchScheduler::Wait(Request* r, std::string* error) {
     while (r->state != kDone) {
         if (r->state == kFlying) {
             const std::shared_ptr<Batch> b = r->batch;
-            if (b->ticket && !b->has_waiter) CompleteLocked(lk, b);      // nobody waits for this batch yet: this thread does
-            else b->cv.wait(lk);                                          // (being submitted, or somebody else waits)
+            if (b->ticket && !b->has_waiter) {                            // nobody waits for this batch yet: this thread does
+                CompleteLocked(lk, b);
+            } else {                                                      // (being submitted, or somebody else waits)
+                r->sleeping = true;
+                r->cv.wait(lk);
+                r->sleeping = false;
+            }
             continue;
         }
         // still queued: both lanes are taken (or a pump is under way).  Help the oldest batch nobody waits for.
@@ -110,8 +120,10 @@ int BatchScheduler::Wait(Request* r, std::string* error) {
         for (const std::shared_ptr<Batch>& b : flying_)
             if (b->ticket && !b->has_waiter) { help = b; break; }
         if (help) { CompleteLocked(lk, help); continue; }
-        if (!pumping_ && lanes_busy_ < kLanes) { PumpLocked(lk); continue; }
-        queue_cv_.wait(lk);
+        if (MayPumpLocked()) { PumpLocked(lk); continue; }
+        r->sleeping = true;
+        r->cv.wait(lk);
+        r->sleeping = false;
     }
     const int rc = r->rc;
     if (error) *error = r->error;
@@ -126,6 +138,7 @@ int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, flo
         if (queue_.empty() && lanes_busy_ == 0 && !pumping_) {
             // The GPU is idle: this block runs at once, by itself, through the engine's synchronous latency path.
             lanes_busy_++;
+            flying_blocks_++;
             stats_.requests++;
             stats_.blocks++;
             stats_.batches++;
@@ -135,6 +148,7 @@ int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, flo
             if (rc != 0 && error) *error = fe_last_error();
             lk.lock();
             lanes_busy_--;
+            flying_blocks_--;
             PumpLocked(lk);
             return rc;
         }
@@ -151,20 +165,33 @@ void BatchScheduler::CompleteLocked(std::unique_lock<std::mutex>& lk, const std:
     const std::string msg = rc != 0 ? fe_last_error() : "";
     lk.lock();
     b->ticket = nullptr;
-    for (Request* q : b->reqs) {
+    std::vector<Request*> settled;
+    settled.swap(b->reqs);
+    for (Request* q : settled) {
         q->rc = rc;
         if (rc != 0) q->error = msg;
-        q->state = kDone;                   // (a request is not touched by the scheduler after this: its thread may free it)
     }
     b->done = true;
     flying_.erase(std::remove(flying_.begin(), flying_.end(), b), flying_.end());
     lanes_busy_--;
+    flying_blocks_ -= b->blocks;
     PumpLocked(lk);                         // everything that queued up meanwhile leaves before anybody is woken
-    b->cv.notify_all();
+    // (PumpLocked let go of the lock while it was in the engine; the settled requests were still kFlying then, so
+    //  their threads could not free them.  From here to the end the lock is held.)
+    for (Request* q : settled) {
+        q->state = kDone;
+        if (q->sleeping) q->cv.notify_one();
+    }
+}
+
+// A batch may leave now: the GPU is idle, or it holds one batch and the queue has grown at least as big.
+bool BatchScheduler::MayPumpLocked() const {
+    if (pumping_ || queue_.empty() || lanes_busy_ >= kLanes) return false;
+    return lanes_busy_ == 0 || queued_blocks_ >= flying_blocks_;
 }
 
 void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
-    while (!pumping_ && lanes_busy_ < kLanes && !queue_.empty()) {
+    while (MayPumpLocked()) {
         pumping_ = true;
         const std::shared_ptr<Batch> b = std::make_shared<Batch>();
         const size_t cap = static_cast<size_t>(g_max_batch.load());
@@ -178,6 +205,9 @@ void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
             blocks += r->blocks;
             b->reqs.push_back(r);
         }
+        b->blocks = blocks;
+        queued_blocks_ -= blocks;
+        flying_blocks_ += blocks;
         if (lanes_busy_ > 0) stats_.overlapped++;
         lanes_busy_++;
         stats_.batches++;
@@ -225,9 +255,24 @@ void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
             for (Request* r : b->reqs) r->state = kDone;
             b->done = true;
             lanes_busy_--;
+            flying_blocks_ -= b->blocks;
         }
-        b->cv.notify_all();                 // threads that found their request "being submitted"
-        queue_cv_.notify_all();             // threads whose request has just left the queue
+        if (rc != 0) {
+            for (Request* r : b->reqs)
+                if (r->sleeping) r->cv.notify_one();    // settled (one by one, above)
+            b->reqs.clear();
+        } else {
+            // ONE sleeping thread becomes the batch's waiter: one of its own, else one whose request is still queued
+            // (it helps, Wait); the others sleep on until their request is settled.  If every thread is busy elsewhere
+            // the batch is picked up by the first that comes to wait or to submit.
+            Request* waker = nullptr;
+            for (Request* r : b->reqs)
+                if (r->sleeping) { waker = r; break; }
+            if (!waker)
+                for (Request* r : queue_)
+                    if (r->sleeping) { waker = r; break; }
+            if (waker) waker->cv.notify_one();
+        }
     }
 }
 

@@ -7,14 +7,16 @@
 // a run-ahead chunk of up to N blocks when the processor reads ahead of its reader, sound_processor.h).
 //
 // A request is submitted without waiting (Submit) and collected later (Wait); Process() is the two
-// back to back.  The combiner keeps at most kLanes batches on the GPU.  A request that finds a lane free
-// leaves at once as a batch of its own — nothing is ever added to a lone stream's latency, there is no
-// collection window and no dispatcher thread — and requests that arrive while both lanes are busy queue up;
-// whichever thread next sees a batch complete submits everything queued as the next batch BEFORE it wakes
-// anybody, so the GPU never waits for a sleeping thread.  Batches form exactly when there is contention and
-// grow with it.  Two batches in flight sit on the engine's two launch lanes (folve_engine.h,
-// fe_batch_submit): while one batch's K3 writes results to host memory, the other's K1 already reads its
-// PCM — both directions of the bus at work.
+// back to back.  A request that finds the GPU idle leaves at once as a batch of its own — nothing is ever
+// added to a lone stream's latency, there is no collection window and no dispatcher thread — and requests
+// that arrive while a batch is on the GPU queue up; whichever thread next sees a batch complete submits
+// everything queued as the next batch BEFORE it wakes anybody, so the GPU never waits for a sleeping thread.
+// Batches form exactly when there is contention and grow with it.  A SECOND batch goes to the GPU while one is
+// still running only when the queue holds at least as many blocks as that batch (two populations of files
+// taking turns: the GPU always has the next batch queued behind the current one); a trickle of small batches
+// beside a big one would only multiply the fixed cost of a launch chain.  Inside the engine a big batch is a
+// duplex pipeline over two launch lanes (folve_engine.h, fe_batch_submit): while one chunk's K3 writes
+// results to host memory, the next chunk's K1 already reads its PCM — both directions of the bus at work.
 //
 // The threads that wait are the only workers: a thread whose request is in a batch nobody waits for yet
 // becomes that batch's waiter (fe_ticket_wait), settles every request in it, submits the next batch and
@@ -26,7 +28,7 @@
 // as a lone block and are bit-identical to it.
 #pragma once
 
-#include <condition_variable>
+#include <condition_variable>   // (Request, in the .cpp, holds one per sleeping thread)
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -80,7 +82,7 @@ private:
         fe_ticket* ticket = nullptr;
         bool has_waiter = false;
         bool done = false;
-        std::condition_variable cv;             // the batch's other threads sleep here
+        long long blocks = 0;
     };
     enum State { kQueued = 0, kFlying, kDone };
 
@@ -90,10 +92,12 @@ private:
     void RunAlone(Request* r);                                            // synchronous engine call for one request
 
     std::mutex mu_;
-    std::condition_variable queue_cv_;          // requests still queued sleep here until a pump takes them
     std::deque<Request*> queue_;
     std::vector<std::shared_ptr<Batch>> flying_;
     int lanes_busy_ = 0;                        // batches on the GPU + batches being submitted + lone synchronous calls
+    long long queued_blocks_ = 0;               // blocks in queue_
+    long long flying_blocks_ = 0;               // blocks in the batches counted by lanes_busy_
+    bool MayPumpLocked() const;
     bool pumping_ = false;                      // one thread at a time turns the queue into batches (keeps submission order)
     Stats stats_;
 };

@@ -59,6 +59,7 @@ struct Tuning {
     // when the descriptors sit in page-locked memory (2 us at the start of each of the three kernels)
     const struct StreamJob* one_job = nullptr;
     bool host_io = false;   // set per call: PCM in and out are page-locked HOST memory (zero-copy single-block path)
+    bool in_resident = false;   // ... but the input has been copied into device memory already (big batches: DMA in, kernels write out)
 };
 
 // What the filter's populated-row bitmaps allow K2 to assume (computed once at commit).

@@ -1537,7 +1537,7 @@ struct FwdLaunch {
         if constexpr (L == 13) {
             // the one-block call from host memory: ONE 1024-thread workgroup, a half per channel, both
             // transforms at once (one workgroup per CU: latency is all that counts here)
-            if (tn.host_io && tn.fft_form == 0 && f.cin == 2 && pairs_ok && (long long)njobs * max_blocks <= 64) {
+            if (tn.host_io && !tn.in_resident && tn.fft_form == 0 && f.cin == 2 && pairs_ok && (long long)njobs * max_blocks <= 64) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * WaveGeom<L>::NT);
                 if (tn.one_job) hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f);
                 else hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, jobs, StreamJob{}, f);
