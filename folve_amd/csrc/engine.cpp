@@ -1382,6 +1382,14 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "FFT form must be 0, 1 or 2");
             e->tuning.fft_form = value;
             return FE_OK;
+        case FE_TUNE_WALK_LPB:
+            if (value != 0 && value != 1 && value != 2 && value != 4) return fail(FE_ERR_PARAM, "lanes per bin must be 0, 1, 2 or 4");
+            e->tuning.walk_lpb = value;
+            return FE_OK;
+        case FE_TUNE_WALK_TILES:
+            if (value < 0 || value > 64) return fail(FE_ERR_PARAM, "time tiles must be 0 .. 64");
+            e->tuning.walk_tiles = value;
+            return FE_OK;
         case FE_TUNE_LANES:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "lanes must be 0 (automatic), 1 or 2");
             e->tuning_single_lane = value == 1;

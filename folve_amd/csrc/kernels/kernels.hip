@@ -81,6 +81,15 @@ __device__ __forceinline__ bool mask_bit(uint64_t lo, uint64_t hi, uint64_t top,
     return ((j < 64 ? lo >> j : j < 128 ? hi >> (j - 64) : top >> (j - 128)) & 1) != 0;
 }
 
+// Running maximum of a stream (non-negative floats order like their bit patterns).  Every wavefront of every block
+// of a stream ends here, and atomics on ONE address serialise in L2 (12 - 16 ns each: a 256-block call of one
+// 8-channel stream spent 0.4 ms in 32 768 of them).  A running maximum rises rarely, so look first — at L2, past the
+// CU's own cache, which an atomic does not update — and leave the atomic to the few wavefronts that raise it.
+__device__ __forceinline__ void peak_raise(unsigned int* p, float v) {
+    const unsigned int bits = __float_as_uint(v);
+    if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
+}
+
 __device__ __forceinline__ int ring_slot(int slot0, int rel, int ring) {
     int s = (slot0 + rel) % ring;
     return s < 0 ? s + ring : s;
@@ -167,9 +176,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += G::NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
-    const int b = blockIdx.x;
+    // grid (8 * channels, blocks / 8, streams): the channels of a block are dispatched together and — workgroup ids
+    // going round the 8 XCDs — land on ONE XCD, so the strided reads of the same interleaved frames meet in its L2
+    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
     if (b >= job.nblocks) return;
-    const int c = blockIdx.y;
+    const int c = blockIdx.x >> 3;
     const int tid = threadIdx.x;
     const int cin = f.cin;
     const long long f0 = (long long)b * P;               // first frame of the block
@@ -210,6 +221,67 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
 // over-fetch; half of stage A's inputs are zero; the two real spectra come out of the symmetry
 //     ZL[k] = (Z[k] + conj Z[2P-k]) / 2,   ZR[k] = (Z[k] - conj Z[2P-k]) / (2i).
 // ---------------------------------------------------------------------------
+// K1 for streams of four or more (an even number of) channels: one workgroup per (block, channel PAIR).  A frame of
+// C interleaved channels holds the pair (2p, 2p+1) as 8 adjacent bytes: the workgroup loads those — half the load
+// instructions of the per-channel kernel, each using 8 of every 32 bytes it touches instead of 4 — keeps both channels'
+// samples in registers (only the lower half of z is data: 8 elements per thread and channel) and transforms one channel
+// after the other in the same LDS image.  grid (8 * pairs, blocks / 8, streams), as forward_kernel.
+template <int LOG2P>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
+    constexpr int H1 = (N1 + 1) / 2;                          // rows n1 < H1 hold data (m = n1*N2 + n2 < P/2); N1 == 1: guarded below
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    const StreamJob job = jobs[blockIdx.z];
+    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
+    if (b >= job.nblocks) return;
+    const int c0 = (blockIdx.x >> 3) * 2;
+    const int tid = threadIdx.x;
+    const int cin = f.cin;
+    const long long f0 = (long long)b * P;
+    const float* __restrict__ in = job.in + c0;
+    float2 ev[COLS][H1], od[COLS][H1];                         // frames 2m and 2m + 1: (channel c0, channel c0 + 1)
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        const int n2 = tid + c * NT;
+#pragma unroll
+        for (int n1 = 0; n1 < H1; ++n1) {
+            const int m = n1 * N2 + n2;
+            const long long fr = f0 + 2 * m;
+            const bool on = n2 < N2 && m < P / 2;
+            ev[c][n1] = (on && fr < job.nframes) ? gld(reinterpret_cast<const float2*>(in + fr * cin)) : float2{0.f, 0.f};
+            od[c][n1] = (on && fr + 1 < job.nframes) ? gld(reinterpret_cast<const float2*>(in + (fr + 1) * cin)) : float2{0.f, 0.f};
+        }
+    }
+    const int slot = ring_slot(job.slot0, b, job.ring);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1) __syncthreads();                          // the first channel's split has read the image
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const int n2 = tid + c * NT;
+            if ((N2 % NT) != 0 && n2 >= N2) continue;
+            float2 v[N1];
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) {
+                if (n1 < H1) v[n1] = h == 0 ? float2{ev[c][n1].x, od[c][n1].x} : float2{ev[c][n1].y, od[c][n1].y};
+                else v[n1] = float2{0.f, 0.f};                // the zero padding of [x | 0]
+            }
+            stage_a_column<LOG2P, false>(s, f.twa, n2, v);
+        }
+        __syncthreads();
+        stage_b<LOG2P, false>(s, twb_l, tid);
+        float2 wsp[SplitGeom<LOG2P>::CNT];
+        split_prefetch<LOG2P>(wsp, f.tw, tid);
+        __syncthreads();
+        float2* row = job.fdl + ((size_t)(c0 + h) * job.ring + slot) * P;
+        split_and_store<LOG2P>(s, wsp, tid, row, 1.0f);
+    }
+}
+
 template <int LOG2P>
 __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(const StreamJob* __restrict__ jobs,
                                                                                FilterDev f) {
@@ -572,9 +644,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
-    const int b = blockIdx.x;
+    // grid (8 * channels, blocks / 8, streams), as forward_kernel: the 4-byte stores of a block's channels into the
+    // same interleaved frames meet in one XCD's L2 instead of reaching HBM as partial lines at different times
+    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
     if (b >= job.nblocks) return;
-    const int o = blockIdx.y;
+    const int o = blockIdx.x >> 3;
     const int tid = threadIdx.x;
     const int cout = f.cout;
     const float2* __restrict__ y = Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P;
@@ -679,8 +753,132 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     }
     if ((tid & 63) == 0) {
         // non-negative floats order like their bit patterns
-        atomicMax(job.peaks + 0, __float_as_uint(pk_s));
-        atomicMax(job.peaks + 1, __float_as_uint(pk_a));
+        peak_raise(job.peaks + 0, pk_s);
+        peak_raise(job.peaks + 1, pk_a);
+    }
+}
+
+// K3 for streams of four or more (an even number of) output channels: one workgroup per (block, channel PAIR), the
+// counterpart of forward_chpair_kernel.  The two outputs are transformed one after the other in the same LDS image; the
+// first one's samples wait in registers, and every frame's pair leaves as one 8-byte store (half the store instructions
+// of the per-channel kernel, 8 of every 32 bytes of a line instead of 4).  grid (8 * pairs, blocks / 8, streams).
+template <int LOG2P>
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+                                                                             const float2* __restrict__ Y) {
+    using G = WaveGeom<LOG2P>;
+    constexpr int P = 1 << LOG2P;
+    constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
+    constexpr int SLOTS = (N2 / 2 + NT - 1) / NT;            // column pairs per thread
+    constexpr int OUTS = (P / 2 + NT - 1) / NT;
+    __shared__ float2 s[G::LDS_ELEMS + G::TWB];
+    float2* const twb_l = s + G::LDS_ELEMS;
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    const StreamJob job = jobs[blockIdx.z];
+    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
+    if (b >= job.nblocks) return;
+    const int o0 = (blockIdx.x >> 3) * 2;
+    const int tid = threadIdx.x;
+    const int cout = f.cout;
+    const float2* __restrict__ tw = f.tw;
+    float2 first[OUTS];                                       // output o0's samples of this thread's frames
+    float* __restrict__ out = job.out + o0;
+    const long long fb = (long long)b * P;
+    float pk_s = 0.0f, pk_a = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float2* __restrict__ y = Y + ((size_t)job.yunit0 + (size_t)(o0 + h) * job.nblocks + b) * P;
+        if (h == 1) __syncthreads();                          // output o0's samples have been read from the image
+        // ---- loads: the two columns of each slot, and the twiddles of the first ----
+        float2 ya[SLOTS][N1], yb[SLOTS][N1], wa[SLOTS][N1];
+    #pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int p = tid + q * NT;
+            if (p < N2 / 2) {
+                const int ca = p, cb = (p == 0) ? N2 / 2 : N2 - p;
+    #pragma unroll
+                for (int n1 = 0; n1 < N1; ++n1) {
+                    ya[q][n1] = y[n1 * N2 + ca];
+                    yb[q][n1] = y[n1 * N2 + cb];
+                    wa[q][n1] = tw[n1 * N2 + ca];                 // e^(-i*pi*k/P), k = n1*N2 + ca
+                }
+            }
+        }
+        // ---- fold in registers, stage A, rows to LDS ----
+    #pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int p = tid + q * NT;
+            if (p < N2 / 2) {
+                float2 za[N1], zb[N1];
+                if (p != 0) {
+                    // k = n1*N2 + p  <->  P - k = (N1-1-n1)*N2 + (N2 - p);  e^(-i*pi*(P-k)/P) = -conj(e^(-i*pi*k/P))
+    #pragma unroll
+                    for (int n1 = 0; n1 < N1; ++n1) {
+                        const float2 a = ya[q][n1], bb = yb[q][N1 - 1 - n1];
+                        const float2 e = cadd_conj(a, bb);
+                        const float2 dd = csub_conj(a, bb);
+                        const float2 oo = cmulc(dd, wa[q][n1]);
+                        za[n1] = cadd_i(e, oo);
+                        zb[N1 - 1 - n1] = conj_csub_i(e, oo);
+                    }
+                } else {
+                    // column 0: k = n1*N2 <-> (N1-n1)*N2 (k = 0 is the packed (DC, Nyquist) bin);
+                    // column N2/2: k = n1*N2 + N2/2 <-> (N1-1-n1)*N2 + N2/2.  Both pair inside the column.
+    #pragma unroll
+                    for (int n1 = 0; n1 < N1; ++n1) {
+                        if (n1 == 0) {
+                            const float2 y0 = ya[q][0];
+                            za[0] = float2{y0.x + y0.y, y0.x - y0.y};
+                        } else {
+                            const float2 a = ya[q][n1], bb = ya[q][N1 - n1];
+                            const float2 e = cadd_conj(a, bb);
+                            const float2 dd = csub_conj(a, bb);
+                            const float2 oo = cmulc(dd, wa[q][n1]);
+                            za[n1] = cadd_i(e, oo);
+                        }
+                        const float2 a = yb[q][n1], bb = yb[q][N1 - 1 - n1];
+                        const float2 e = cadd_conj(a, bb);
+                        const float2 dd = csub_conj(a, bb);
+                        const float2 oo = cmulc(dd, tw[n1 * N2 + N2 / 2]);
+                        zb[n1] = cadd_i(e, oo);
+                    }
+                }
+                const int ca = p, cb = (p == 0) ? N2 / 2 : N2 - p;
+                stage_a_column<LOG2P, true>(s, f.twa, ca, za);
+                stage_a_column<LOG2P, true>(s, f.twa, cb, zb);
+            }
+        }
+        __syncthreads();
+        stage_b<LOG2P, true>(s, twb_l, tid);
+        __syncthreads();
+        // ---- transposed read: consecutive lanes take consecutive output frames ----
+#pragma unroll
+        for (int c = 0; c < OUTS; ++c) {
+            const int q = P / 2 + tid + c * NT;              // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
+            if (q >= P) continue;
+            const float2 z = s[G::at(q)];
+            if (h == 0) { first[c] = z; continue; }
+            const long long fr = fb + 2 * q - P;
+            const float2 e = float2{first[c].x, z.x}, o = float2{first[c].y, z.y};   // frames fr and fr + 1: (o0, o0 + 1)
+            if (fr < job.nframes) {
+                gst(reinterpret_cast<float2*>(out + fr * cout), e);
+                pk_s = fmaxf(pk_s, fmaxf(e.x, e.y));
+                pk_a = fmaxf(pk_a, fmaxf(fabsf(e.x), fabsf(e.y)));
+            }
+            if (fr + 1 < job.nframes) {
+                gst(reinterpret_cast<float2*>(out + (fr + 1) * cout), o);
+                pk_s = fmaxf(pk_s, fmaxf(o.x, o.y));
+                pk_a = fmaxf(pk_a, fmaxf(fabsf(o.x), fabsf(o.y)));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pk_s = fmaxf(pk_s, __shfl_xor(pk_s, off, 64));
+        pk_a = fmaxf(pk_a, __shfl_xor(pk_a, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        peak_raise(job.peaks + 0, pk_s);
+        peak_raise(job.peaks + 1, pk_a);
     }
 }
 
@@ -883,8 +1081,8 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
         pk_a = fmaxf(pk_a, __shfl_xor(pk_a, off, 64));
     }
     if ((tid & 63) == 0) {
-        atomicMax(job.peaks + 0, __float_as_uint(pk_s));
-        atomicMax(job.peaks + 1, __float_as_uint(pk_a));
+        peak_raise(job.peaks + 0, pk_s);
+        peak_raise(job.peaks + 1, pk_a);
     }
 }
 
@@ -997,8 +1195,8 @@ __global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void inverse_pair_kernel(c
         pk_a = fmaxf(pk_a, __shfl_xor(pk_a, off, 64));
     }
     if ((t & 63) == 0) {
-        atomicMax(job.peaks + 0, __float_as_uint(pk_s));
-        atomicMax(job.peaks + 1, __float_as_uint(pk_a));
+        peak_raise(job.peaks + 0, pk_s);
+        peak_raise(job.peaks + 1, pk_a);
     }
 }
 
@@ -1279,19 +1477,44 @@ __device__ __forceinline__ bool static_all(F&& f) {
     return static_all_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int KR, int D, bool PIN = false, int NACC = 6>
-__global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 * KR + D) + 12 <= 168) ? 3 : 2) void mac_walk_kernel(
-    const StreamJob* __restrict__ jobs, FilterDev f, float2* __restrict__ Y) {
+// Several lanes per bin (LPB = 2 or 4) carry filters of more than KR rows: lane `sub` of a bin's group holds rows
+// sub*KR .. sub*KR + KR - 1 of G and a window of the spectra those rows meet — the blocks KR*sub further back in time.
+// Only lane 0 of a group loads from memory.  The element that leaves a lane's window at a step (block t - KR in the
+// lane's own frame) is exactly what the next lane needs as ITS newest element at that step: it is handed down with one
+// DPP row shift per register before its slot is re-used, so every X element is still read from HBM once per call
+// however long the filter.  The partial sums of a group are added with two quad-permute DPP steps and every lane of
+// the group stores the (same) result.  K + 1 <= 33 * LPB rows: 65 (512 k taps) with two lanes, 129 (MAXSIZE) with four.
+//
+// Time tiles (`tiles` > 1): a one-stream call does not have enough (bin, output) pairs to fill the chip; its blocks are
+// cut into `tiles` runs of `tile_len`, each walked by its own workgroups (and re-reading the rows of history before it).
+__device__ __forceinline__ float dpp_row_shr1(float v) {
+    // (bound_ctrl: lanes without a source read 0 — no `old` operand to materialise; those lanes' results are never used)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int KR, int D, bool PIN = false, int NACC = 6, int LPB = 1>
+__global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <= 128) ? 4 : (2 * (2 * KR + D) + 12 + (LPB > 1 ? 16 : 0) <= 168) ? 3 : 2) void mac_walk_kernel(
+    const StreamJob* __restrict__ jobs, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
     constexpr int W = KR + D;
+    static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per bin");
     const StreamJob job = jobs[blockIdx.z];
-    const int o = blockIdx.y;
-    const int nb = job.nblocks;
+    const int o = blockIdx.y / tiles;
+    const int tb = (blockIdx.y - o * tiles) * tile_len;     // first block of this workgroup's time tile
+    if (tb >= job.nblocks) return;
+    const int nb = min(tile_len, job.nblocks - tb);
     const int P = f.P, K = f.K, ring = job.ring;
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int bin = tid / LPB, sub = tid % LPB;
+    const int jb = sub * KR;                                // this lane's first row of G
+    const bool head = sub == 0;                             // the lane of its group that takes the loaded element
     const unsigned voff = (unsigned)bin * 8u;               // this thread's bin inside any spectrum row
     const bool packed = bin == 0;
     const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
-    const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * nb;
+    const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * job.nblocks + tb;
     if (pe1 > pe0) {
         const PathEntry pth = f.paths[pe0];
         // row bases are wave-uniform (scalar registers); the per-lane part of every address is `voff`
@@ -1306,21 +1529,39 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
         // s_waitcnt vmcnt(N) for block t leaves exactly the D younger loads and the stores in flight;
         // behind a conditional load it would have to assume the worst and drain the prefetch.
         // history: block -j in slot W - j (j = 1 .. K-1); the call's first D blocks in slots 0 .. D-1
-        if (K == KR) {                                      // the common case (K = 32 partitions + 1): no selects
+        if constexpr (LPB == 1) {
+            if (K == KR) {                                  // the common case (K = 32 partitions + 1): no selects
 #pragma unroll
-            for (int j = 0; j < KR; ++j) g[j] = ldrow(Hd + (size_t)j * P);
+                for (int j = 0; j < KR; ++j) g[j] = ldrow(Hd + (size_t)j * P);
 #pragma unroll
-            for (int j = 1; j < KR; ++j) w[W - j] = ldrow(X + (size_t)ring_slot(job.slot0, -j, ring) * P);
+                for (int j = 1; j < KR; ++j) w[W - j] = ldrow(X + (size_t)ring_slot(job.slot0, tb - j, ring) * P);
+            } else {
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const v2f v = ldrow(Hd + (size_t)(j < K ? j : 0) * P);
+                    g[j] = (j < K) ? v : v2f{0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 1; j < KR; ++j) {
+                    const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, j < K ? tb - j : tb, ring) * P);
+                    w[W - j] = (j < K) ? v : v2f{0.f, 0.f};
+                }
+            }
+            w[D] = v2f{0.f, 0.f};
         } else {
+            // per-lane rows: G row jb + j; the window starts KR * sub blocks back.  Slot D (block -KR of the lane's
+            // frame) is loaded too: it is the first element handed down to the next lane.
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
-                const v2f v = ldrow(Hd + (size_t)(j < K ? j : 0) * P);
-                g[j] = (j < K) ? v : v2f{0.f, 0.f};
+                const bool on = jb + j < K;
+                const v2f v = ldrow(Hd + (size_t)(on ? jb + j : 0) * P);
+                g[j] = on ? v : v2f{0.f, 0.f};
             }
 #pragma unroll
-            for (int j = 1; j < KR; ++j) {
-                const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, j < K ? -j : 0, ring) * P);
-                w[W - j] = (j < K) ? v : v2f{0.f, 0.f};
+            for (int j = 1; j <= KR; ++j) {
+                const bool on = jb + j < K;                 // (an element no row will ever meet is a zero)
+                const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, on ? tb - j - jb : tb, ring) * P);
+                w[W - j] = on ? v : v2f{0.f, 0.f};
             }
         }
         // PIN: the in-loop loads are issued by inline asm at the step they belong to and awaited by an
@@ -1329,41 +1570,59 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
         // register limit this kernel runs at), which turns a D-deep prefetch into none.  The window
         // register is the asm's output and the wait's in/out operand, so every use is ordered behind
         // its wait; the kernel must stay free of spills and copies of window registers (checked in the
-        // disassembly: no v_mov of a window register inside the loop).
+        // disassembly: no v_mov of a window register inside the loop; `make check-isa` looks for scratch).
         auto issue = [&](v2f& dst, const float2* rowbase) {
             if constexpr (PIN) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(rowbase) : "memory");
             else dst = ldrow(rowbase);
         };
         // the next row to request, as a pointer that wraps at the ring's end (a handful of scalar
         // instructions per step instead of a slot * row-size product)
-        const float2* xrow = X + (size_t)job.slot0 * P;
+        const float2* xrow = X + (size_t)ring_slot(job.slot0, tb, ring) * P;
         const float2* const xend = X + (size_t)ring * P;
         int left = nb;                                      // blocks not yet requested
-        auto advance = [&]() {                              // past the call's last block: stay on it (re-read, never used)
+        auto advance = [&]() {                              // past the tile's last block: stay on it (re-read, never used)
             if (left > 1) { xrow += P; xrow = (xrow == xend) ? X : xrow; --left; }
         };
-        w[D] = v2f{0.f, 0.f};
         if constexpr (PIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G and the history have arrived: the count starts here
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             issue(w[d], xrow);
             advance();
         }
+        // Every step waits for the element of the NEXT step (below); the first step's own element is awaited here.
+        // A wait is an asm statement that "writes" the window register (that is what orders its uses behind it), and
+        // hipcc pads ten to thirteen s_nop between such a statement and an inline-asm MAC that reads the register
+        // right after it (it cannot see what the asm does): with the wait one step ahead of the use the padding is gone.
+        if constexpr (PIN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(D - 1) : "memory");
+        if constexpr (LPB > 1) {
+            // (the hand-down of block tb - KR: slot D of the neighbour, read before the loop's first issue re-uses it)
+            const float hx = dpp_row_shr1(w[D].x), hy = dpp_row_shr1(w[D].y);
+            w[0].x = head ? w[0].x : hx;
+            w[0].y = head ? w[0].y : hy;
+        }
         float2* __restrict__ yrow = Y + yrow0 * P;          // uniform: advances one row per step
         for (int t0 = 0; t0 < nb; t0 += W) {
             // unrolled by W through a fold expression (every window index a compile-time constant; the
-            // loop unroller gives up on a body of this size), with an exit after the call's last block
+            // loop unroller gives up on a body of this size), with an exit after the tile's last block
             const bool more = static_all<W>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 // block t + D rides in while blocks t .. t+D-1 are used: its slot held block t - KR, no longer needed
                 issue(w[(u + D) % W], xrow);
                 advance();
+                // the NEXT step's element.  For the lanes of a group behind the head it is the element that leaves the
+                // lane before it at that step (block t + 1 - KR of that lane's frame, in the slot the next issue re-uses):
+                // handed down by one DPP row shift per register; the head lanes take what was loaded.
                 if constexpr (PIN) {
-                    // younger than the load of block t: the D loads after it and the stores of the steps in
-                    // between — D of them once the walk is D steps old (fewer before: the count below is
-                    // exact in the first round and merely stricter at the start of later ones)
-                    constexpr int N = D + (u < D ? u : D);
-                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[u % W]) : "n"(N) : "memory");
+                    // younger than the load of block t + 1: the D - 1 loads after it and the stores of the steps since it
+                    // was issued — D - 1 of them once the walk is that old (fewer before: the count below is exact in the
+                    // first round and merely stricter at the start of later ones)
+                    constexpr int N = (D - 1) + (u < D - 1 ? u : D - 1);
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[(u + 1) % W]) : "n"(N) : "memory");
+                }
+                if constexpr (LPB > 1) {
+                    const float hx = dpp_row_shr1(w[(u + 1 + D) % W].x), hy = dpp_row_shr1(w[(u + 1 + D) % W].y);
+                    w[(u + 1) % W].x = head ? w[(u + 1) % W].x : hx;
+                    w[(u + 1) % W].y = head ? w[(u + 1) % W].y : hy;
                 }
                 // NACC accumulators — the real-part and the imaginary-part products of every (NACC/2)-th partition —
                 // so that every v_pk_fma_f32 is NACC instructions away from the one it depends on (a MAC's own
@@ -1389,6 +1648,12 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 <= 128) ? 4 : (2 * (2 *
                 v2f sum = sre + sim;
                 sum.x = packed ? sre.x : sum.x;
                 sum.y = packed ? -sim.x : sum.y;
+                if constexpr (LPB >= 2) {                    // the group's partial sums: every lane ends up with the total
+                    sum.x += dpp_quad<0xB1>(sum.x); sum.y += dpp_quad<0xB1>(sum.y);
+                }
+                if constexpr (LPB >= 4) {
+                    sum.x += dpp_quad<0x4E>(sum.x); sum.y += dpp_quad<0x4E>(sum.y);
+                }
                 // unconditional: a store under a branch would not count in the compiler's vmcnt arithmetic
                 // and halve the prefetch depth
                 *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
@@ -1544,7 +1809,12 @@ struct FwdLaunch {
                 return hipGetLastError();
             }
         }
-        dim3 grid(max_blocks, f.cin, njobs), block(WaveGeom<L>::NT);
+        if (tn.fft_form != 1 && pairs_ok && f.cin >= 4 && f.cin % 2 == 0) {   // many channels: a workgroup per channel pair
+            dim3 grid(8 * (f.cin / 2), (max_blocks + 7) / 8, njobs), block(WaveGeom<L>::NT);
+            hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, block, 0, st, jobs, f);
+            return hipGetLastError();
+        }
+        dim3 grid(8 * f.cin, (max_blocks + 7) / 8, njobs), block(WaveGeom<L>::NT);
         hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f);
         return hipGetLastError();
     }
@@ -1576,7 +1846,12 @@ struct InvLaunch {
                 return hipGetLastError();
             }
         }
-        dim3 grid(max_blocks, f.cout, njobs), block(NT);
+        if (tn.fft_form != 1 && pairs_ok && f.cout >= 4 && f.cout % 2 == 0) {
+            dim3 grid(8 * (f.cout / 2), (max_blocks + 7) / 8, njobs), block(NT);
+            hipLaunchKernelGGL(inverse_chpair_kernel<L>, grid, block, 0, st, jobs, f, Y);
+            return hipGetLastError();
+        }
+        dim3 grid(8 * f.cout, (max_blocks + 7) / 8, njobs), block(NT);
         hipLaunchKernelGGL(inverse_kernel<L>, grid, block, 0, st, jobs, f, Y);
         return hipGetLastError();
     }
@@ -1709,32 +1984,85 @@ void fill_fft_tables(int log2P, float2* dst, int off[4]) {
 }
 
 // Form choice.  A single block per call is a pure stream over K rows (mac_kernel<1>, HBM-bound).
-// Run-ahead calls (>= 12 blocks): the whole-call walk when every output has one dense path of at
-// most 33 rows and the launch still fills the chip with one workgroup per (256 bins, output,
-// stream) — every X row read once; otherwise the 16-output sliding window, which also skips
-// unpopulated rows of sparse filters and splits long calls into time tiles for parallelism.
+// Run-ahead calls (>= 12 blocks): the whole-call walk when every output has one mostly populated path of at most
+// 132 rows — every X row read once; otherwise the 16-output sliding window, which also skips unpopulated rows of
+// sparse filters.  The walk's shape (rows per lane, lanes per bin, time tiles) is chosen so that the launch has
+// at least two wavefronts per SIMD: a batch of many streams takes one lane per bin, a lone stream spreads its filter
+// over the lanes of a group and its blocks over time tiles.
+namespace {
+struct WalkShape { int kr, lpb, tiles, tile_len; };
+// rows of G per lane for `lpb` lanes per bin: the smallest instantiated window that holds ceil(rows / lpb); 0: none
+int walk_rows_per_lane(int rows, int lpb) {
+    const int need = (rows + lpb - 1) / lpb;
+    if (need <= 9 && lpb != 2) return 9;
+    if (need <= 17) return 17;
+    if (need <= 33) return 33;
+    return 0;
+}
+bool choose_walk(const FilterDev& f, int njobs, int max_blocks, WalkShape* out) {
+    const int rows = f.K;
+    if (rows > 132 || f.P < 256) return false;
+    const long long want = 2048;                               // wavefronts: two per SIMD
+    // a time tile re-reads `rows` rows of history: no shorter than 32 blocks, nor than half the filter
+    const int min_tile = rows / 2 > 32 ? rows / 2 : 32;
+    out->kr = 0;
+    for (int lpb = 1; lpb <= 4; lpb *= 2) {                    // fewest lanes per bin first: least arithmetic overhead,
+        const int kr = walk_rows_per_lane(rows, lpb);          // widest rows per wavefront
+        if (!kr) continue;
+        const long long waves = (long long)njobs * f.cout * (f.P / 64) * lpb;
+        int tiles = 1;
+        while (waves * tiles < want && max_blocks / (tiles * 2) >= min_tile) tiles *= 2;
+        out->kr = kr;
+        out->lpb = lpb;
+        out->tiles = tiles;
+        out->tile_len = (max_blocks + tiles - 1) / tiles;
+        if (waves * tiles >= want) break;
+    }
+    return out->kr != 0;
+}
+template <int KR, int D, int LPB>
+void launch_walk(const StreamJob* jobs, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, hipStream_t st) {
+    dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
+    hipLaunchKernelGGL((mac_walk_kernel<KR, D, true, 6, LPB>), grid, block, 0, st, jobs, f, Y, w.tiles, w.tile_len);
+}
+}  // namespace
+
 hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, float2* Y, int time_tile,
                       const MacShape& shape, const Tuning& tn, hipStream_t st) {
     const int P2 = f.P / 2;
     int form = tn.mac_form;
-    const bool walk_ok = shape.single_path && f.K <= 33 && f.P >= 256;
-    // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
-    // waves start together and read 2 KB of a row between them: DRAM locality)
-    const int walk_threads = 256;
+    WalkShape ws{};
+    const bool walk_ok = shape.single_path && choose_walk(f, njobs, max_blocks, &ws);
+    if (tn.walk_lpb > 0 && walk_ok) {                           // tests: pin the lanes per bin / the time tiles
+        const int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) ? walk_rows_per_lane(f.K, tn.walk_lpb) : 0;
+        if (kr) { ws.lpb = tn.walk_lpb; ws.kr = kr; }
+    }
+    if (tn.walk_tiles > 0 && walk_ok) {
+        ws.tiles = tn.walk_tiles;
+        ws.tile_len = (max_blocks + ws.tiles - 1) / ws.tiles;
+    }
     if (form == 100 && !walk_ok) form = 0;
     if (form == 0) {
-        if (time_tile >= 12) {
-            const long long wgs = (long long)njobs * f.cout * (f.P / 256);
-            form = (walk_ok && shape.dense && wgs >= 1024) ? 100 : 16;
-        } else if (time_tile >= 6) form = 8;
+        if (time_tile >= 12) form = (walk_ok && shape.dense) ? 100 : 16;
+        else if (time_tile >= 6) form = 8;
         else if (time_tile >= 4) form = 4;
         else form = 1;
     }
     if (form == 100) {
-        dim3 grid(f.P / walk_threads, f.cout, njobs), block(walk_threads);
-        if (f.K <= 9) hipLaunchKernelGGL((mac_walk_kernel<9, 7, true>), grid, block, 0, st, jobs, f, Y);
-        else if (f.K <= 17) hipLaunchKernelGGL((mac_walk_kernel<17, 7, true>), grid, block, 0, st, jobs, f, Y);
-        else hipLaunchKernelGGL((mac_walk_kernel<33, 7, true>), grid, block, 0, st, jobs, f, Y);
+        // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
+        // waves start together and read 2 KB of a row between them: DRAM locality)
+        if (ws.lpb == 1) {
+            if (ws.kr == 9) launch_walk<9, 7, 1>(jobs, njobs, f, Y, ws, st);
+            else if (ws.kr == 17) launch_walk<17, 7, 1>(jobs, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 1>(jobs, njobs, f, Y, ws, st);
+        } else if (ws.lpb == 2) {
+            if (ws.kr == 17) launch_walk<17, 15, 2>(jobs, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 2>(jobs, njobs, f, Y, ws, st);
+        } else {
+            if (ws.kr == 9) launch_walk<9, 15, 4>(jobs, njobs, f, Y, ws, st);
+            else if (ws.kr == 17) launch_walk<17, 15, 4>(jobs, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 4>(jobs, njobs, f, Y, ws, st);
+        }
         return hipGetLastError();
     }
     if (form == 4 || form == 8 || form == 16) {

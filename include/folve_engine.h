@@ -173,10 +173,13 @@ int fe_batch_get_peaks(fe_stream *const *streams, int n, float *peak_signed, flo
 enum {
     FE_TUNE_FWD_RUN = 0,   /* K1 walker: consecutive blocks per workgroup (1..4096) */
     FE_TUNE_INV_RUN = 1,   /* K3 walker: consecutive blocks per workgroup */
-    FE_TUNE_MAC_FORM = 2,  /* K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk */
+    FE_TUNE_MAC_FORM = 2,  /* K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk (also for
+                              sparse filters, whose empty rows of G are zeros in memory) */
     FE_TUNE_FFT_FORM = 3,  /* K1/K3: 1 general kernels only, 2 walkers whenever the shape allows */
     FE_TUNE_FAIL_NEXT = 4, /* fault injection: the n-th launch round of this engine from now fails with FE_ERR_DEVICE (1 = the next;
                               negative: every round until the knob is set to 0) */
+    FE_TUNE_WALK_LPB = 6,  /* K2 whole-call walk: lanes per bin (1, 2, 4; the filter's rows of G are spread over them) */
+    FE_TUNE_WALK_TILES = 7,/* K2 whole-call walk: time tiles per call (1 ..) */
     FE_TUNE_LANES = 5      /* fe_batch_submit: 1 = every batch on the engine's own HIP stream, 0 / 2 = two lanes (batches of different
                               streams overlap: one reads its PCM over the bus while the other writes its results back) */
 };

@@ -25,7 +25,7 @@ def _rms(a):
 def tuned(engine):
     """The session engine with every knob back on automatic afterwards."""
     yield engine
-    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0)
+    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0)
 
 
 def test_xlane_exchange_semantics(engine):
@@ -371,3 +371,91 @@ def test_submit_wait_split_matches_the_synchronous_call(tuned, oracle):
     finally:
         for b in bufs:
             L.fe_host_free(b)
+
+
+@pytest.mark.parametrize("size,channels,lpbs", [
+    (204800, 2, (1, 2, 4)),       # K + 1 = 26 rows: mac_walk<33, 1 lane>, <17, 2 lanes>, <9, 4 lanes>
+    (524288, 2, (2, 4)),          # K + 1 = 65 rows (cfg4's filter): <33, 2>, <17, 4>
+    (1048576, 1, (4,)),           # K + 1 = 129 rows (MAXSIZE, zita-config.h:61): <33, 4>
+    (70000, 1, (1, 2, 4)),        # K + 1 = 10 rows: <17, 1>, <17, 2>, <9, 4>
+])
+def test_mac_walk_lanes_per_bin_and_time_tiles(tuned, oracle, size, channels, lpbs):
+    """The whole-call walk with the filter's rows spread over 1 / 2 / 4 lanes of a bin (the window handed down from
+    lane to lane by DPP shifts) and with the call cut into time tiles, against the general MAC kernel on the same
+    calls; state carried into a second call; ragged lengths; and the float64 convolution."""
+    rng = np.random.default_rng(size + channels)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(channels)}
+    sp, flt, _ = make_pair(tuned, oracle, channels, channels, size, paths)
+    P, K = flt.block_size, flt.partitions
+    T = 2 * K + 7 if K <= 32 else K + 9                                  # longer than the filter, not a multiple of anything
+    S = 3
+    lens = [T * P - 777 * s for s in range(S)]
+    xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
+    more = [rng.uniform(-1, 1, (37 * P - 5, channels)).astype(np.float32) for _ in range(S)]
+    tuned.set_tuning(mac_form=1)
+    st = [flt.open_stream(T) for _ in range(S)]
+    ref1 = fa.batch_process(st, xs)
+    ref2 = fa.batch_process(st, more)
+    hd = dense_taps(paths, size)
+    y64 = oracle.linear_convolution_f64(xs[0], hd, channels)
+    assert _rms(ref1[0] - y64) <= TOL
+    for lpb in lpbs:
+        for tiles in (1, 2, 5):
+            tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_tiles=tiles)
+            st = [flt.open_stream(T) for _ in range(S)]
+            y1 = fa.batch_process(st, xs)
+            y2 = fa.batch_process(st, more)
+            for s in range(S):
+                assert _rms(y1[s] - ref1[s]) <= 2e-6, (lpb, tiles, s)
+                assert _rms(y2[s] - ref2[s]) <= 2e-6, (lpb, tiles, s)
+            assert _rms(y1[0] - y64) <= TOL and _rms(y1[0] - y64) / _rms(y64) <= TOL, (lpb, tiles)
+
+
+def test_automatic_walk_shapes_for_one_stream_calls(tuned, oracle):
+    """What launch_mac picks by itself for cfg2's and cfg4's shapes at a 128-block call (one stream: lanes per bin and
+    time tiles so that the launch fills the chip) agrees with the general kernel."""
+    rng = np.random.default_rng(77)
+    for size, C in ((204800, 2), (524288, 8)):
+        paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+        _, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+        P = flt.block_size
+        x = rng.uniform(-1, 1, (128 * P - 99, C)).astype(np.float32)
+        tuned.set_tuning(mac_form=0, walk_lpb=0, walk_tiles=0)
+        y_auto = flt.open_stream(128).process_blocks(x)
+        tuned.set_tuning(mac_form=1)
+        y_gen = flt.open_stream(128).process_blocks(x)
+        assert _rms(y_auto - y_gen) <= 2e-6
+        c = C - 1
+        y64 = oracle.linear_convolution_f64(x[:40 * P], {(c, c): dense_taps(paths, size)[(c, c)]}, C)[:, c]
+        assert _rms(y_auto[:40 * P, c] - y64) <= TOL
+
+
+@pytest.mark.parametrize("channels,size", [(4, 20000), (8, 20000), (6, 3000), (64, 128)])
+def test_channel_pair_kernels_match_the_per_channel_ones(tuned, oracle, channels, size):
+    """Streams of four or more channels: forward_chpair / inverse_chpair (a workgroup per channel pair, 8-byte loads
+    and stores of interleaved frames) against the per-channel general kernels — the same butterflies on the same
+    numbers, hence the same bits — for P = 8192, 2048 and 128, ragged tails, two calls."""
+    rng = np.random.default_rng(channels * 1000 + size)
+    paths = {}
+    for c in range(channels):
+        paths[(c, (c + 1) % channels)] = [(0, (rng.standard_normal(min(size, 4000)) * 0.05).astype(np.float32))]
+        if c % 3 == 0:
+            paths[(c, c)] = [(size // 2, (rng.standard_normal(size // 2) / np.sqrt(size)).astype(np.float32))]
+    sp, flt, _ = make_pair(tuned, oracle, channels, channels, size, paths)
+    P = flt.block_size
+    lens = [11 * P, 7 * P + 1234 % P, 3 * P - 1]
+    xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
+    more = [rng.uniform(-1, 1, (2 * P + 3, channels)).astype(np.float32) for _ in lens]
+    outs = {}
+    for form in (0, 1):
+        tuned.set_tuning(fft_form=form)
+        st = [flt.open_stream(11) for _ in lens]
+        outs[form] = (fa.batch_process(st, xs), fa.batch_process(st, more), [s_.peaks() for s_ in st])
+    for s_ in range(len(lens)):
+        assert np.array_equal(outs[0][0][s_], outs[1][0][s_])
+        assert np.array_equal(outs[0][1][s_], outs[1][1][s_])
+        assert outs[0][2][s_] == outs[1][2][s_]
+    sp.reset()
+    assert _rms(outs[0][0][1] - sp.run(xs[1])) <= TOL
+    y64 = oracle.linear_convolution_f64(xs[0], dense_taps(paths, size), channels)
+    assert _rms(outs[0][0][0] - y64) <= TOL
