@@ -30,6 +30,8 @@ contract's keys:
   single_block_us — one synchronous stereo block through fe_stream_process (the drop-in call)
   drop_in_threads — the same call from 1 / 16 / 64 host threads at once, each its own folve::SoundProcessor
                  (a C++ child process over include/folve_host.h), with and without the per-GPU combiner
+  configs      — cfg2 (one stereo stream, SantaLucia shape) and cfg4 (96 kHz x 8 channels x 512 k taps) at 256-block
+                 calls: rate, per-kernel ms and roofline (PMC bytes of `bench.py --only-config cfgN`, profiles/traffic.json)
   cpu_baseline — the CPU restatement of zita-convolver's algorithm (oracle/, rebuilt -march=native
                  on this box), all cores and one core, on a bounded sample (N = 1 only)
 """
@@ -186,6 +188,138 @@ def rms(a):
     return float(np.sqrt(np.mean(a * a)))
 
 
+# The other single-GPU configurations of BASELINE.json (parity-test shapes: tests/test_configs_gpu.py), measured the same
+# way as the headline: PCM resident in HBM, T-block run-ahead calls, HIP events per kernel.
+OTHER_CONFIGS = {
+    "cfg2": dict(S=1, C=2, size=204800, populated=178193, rate=44100,
+                 what="one 44.1 kHz stereo stream, SantaLucia-shaped filter (178 193 taps at delay 500 + a dirac, size 204 800: "
+                      "K = 25, 22 populated; /root/reference/demo-filters/SantaLucia/filter-44100.conf:39-53)"),
+    "cfg4": dict(S=1, C=8, size=524288, populated=None, rate=96000,
+                 what="one 96 kHz 8-channel stream, 8 diagonal paths of 524 288 taps (K = 64)"),
+}
+
+
+def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=None, dev=0, check=True, **_):
+    """One filter of C diagonal paths (`populated` taps at offset 500 plus a dirac at 0, or `size` dense taps), S streams,
+    T-block calls.  Returns ms per call (wall clock over `steps` asynchronous calls), per-kernel ms (HIP events, a second
+    loop), and — check=True — the rms deviation of the first call's output from the float64 convolution."""
+    import torch
+    import folve_amd as fa
+    from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS, FE_ASYNC
+    ts = torch.cuda.Stream()
+    eng = fa.Engine(dev, ts.cuda_stream)
+    if tune:
+        eng.set_tuning(**tune)
+    flt = fa.Filter(eng, C, C, size)
+    rng = np.random.default_rng(3)
+    taps = []
+    for c in range(C):
+        h = np.zeros(size, np.float32)
+        if populated:
+            ir = (rng.standard_normal(populated) * np.exp(-np.arange(populated) / 40000.0)).astype(np.float32)
+            h[500:500 + populated] = ir / np.linalg.norm(ir)
+            h[0] += np.float32(0.4)
+            flt.add(c, c, h[500:500 + populated], 500)
+            flt.add(c, c, h[:1], 0)
+        else:
+            h = rng.standard_normal(size).astype(np.float32)
+            h /= np.linalg.norm(h)
+            flt.add(c, c, h)
+        taps.append(h)
+    flt.commit()
+    P, K = flt.block_size, flt.partitions
+    streams = [flt.open_stream(T) for _ in range(S)]
+    with torch.cuda.stream(ts):
+        xs = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
+        ys = [torch.empty_like(x) for x in xs]
+    plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S, FE_DEVICE_PTRS | FE_ASYNC)
+    parity = None
+    if check:
+        plan.run()
+        eng.synchronize()
+        torch.cuda.synchronize()
+        n = min(T, 2 * K + 8) * P                        # long enough for every partition to act
+        x0, y0 = xs[0][:n].cpu().numpy(), ys[0][:n].cpu().numpy()
+        cc = [0, C - 1]
+        ref = conv_f64(x0[:, cc], [taps[c] for c in cc])
+        parity = max(rms(y0[:, cc] - ref), rms(y0[:, cc] - ref) / rms(ref))
+        for st in streams:
+            st.reset()
+    for _ in range(warmup):
+        plan.run()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.set_profiling(True)
+    eng.reset_profile()
+    for _ in range(steps):
+        plan.run()
+    eng.synchronize()
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    kms = {k: v["ms"] / max(1, v["launches"]) for k, v in prof.items()}
+    out = {"streams": S, "channels": C, "taps": size, "block": P, "partitions": K, "populated_partitions": flt.path_partitions(0, 0),
+           "blocks_per_call": T, "ms_per_call": dt * 1e3, "kernels_ms": kms, "msamples_per_s": S * T * P * C / dt / 1e6,
+           "parity_rms": parity}
+    for s_ in streams:
+        s_.close()
+    del xs, ys
+    return out
+
+
+def config_line(name, T, steps=100, tune=None, dev=0, check=True):
+    """The `configs` entry of one configuration: rate at T-block calls, per-kernel times, and its roofline — HBM bytes per
+    launch from the committed rocprofv3 PMC passes of `python bench.py --only-config <name>` (profiles/traffic.json), used
+    only while this run's kernel times agree with the profiled run's."""
+    cfg = OTHER_CONFIGS[name]
+    r = measure_config(T=T, steps=steps, tune=tune, dev=dev, check=check, **cfg)
+    P, K, C, S = r["block"], r["partitions"], r["channels"], r["streams"]
+    units = S * C * T
+    tb = tiled_bytes(P, K, T)
+    kms = r["kernels_ms"]
+    dominant = max(kms, key=kms.get)
+    entry = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            entry = json.load(open(tpath)).get("S%d_T%d_K%d_C%d" % (S, T, K, C)) or {}
+        except Exception:
+            entry = {}
+    by = entry.get("bytes") or {}
+    # (HIP events around a kernel of a few tens of microseconds read 4 - 8 us long: agreement within 25 % or 10 us)
+    ok = bool(by) and all(abs(kms[k] * 1e6 - (entry.get("avg_ns") or {}).get(k, 0)) <= max(0.25 * (entry.get("avg_ns") or {}).get(k, 1), 10e3)
+                          for k in by)
+    note = None
+    if by and not ok:
+        note = "in-run kernel times differ from profile %s's by more than 25 %% (and 10 us): its traffic is not used" % entry.get("profile")
+        by = {}
+    path_bytes = sum(by.values()) if len(by) == 3 else None
+    kernels = {}
+    for k in kms:
+        kernels[k] = {"ms": round(kms[k], 4), "traffic": by.get(k),
+                      "frac": round(by[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if by.get(k) else None,
+                      "frac_of_min_bytes": round(tb[k] * units / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "kernel": (entry.get("kernels") or {}).get(k)}
+    return {"workload": "%s: %s; P=%d, %d blocks per call, PCM resident in HBM" % (name, cfg["what"], P, T),
+            "msamples_per_s": round(r["msamples_per_s"], 1), "ms_per_call": round(r["ms_per_call"], 4),
+            "realtime_factor": round(T * P / (r["ms_per_call"] * 1e-3) / cfg["rate"], 0),
+            "blocks_per_call": T, "partitions": K, "populated_partitions": r["populated_partitions"],
+            "parity_rms": r["parity_rms"],
+            "roofline": {"bound": "hbm", "kernel": {"forward": "K1 forward", "mac": "K2 mac", "inverse": "K3 inverse"}[dominant],
+                         "achieved": round(by[dominant] / (kms[dominant] * 1e-3) / 1e9, 1) if by.get(dominant) else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kernels[dominant]["frac"], "traffic": by.get(dominant),
+                         "traffic_source": entry.get("profile"), "traffic_note": note,
+                         "path": {"frac": round(path_bytes / (r["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if path_bytes else None,
+                                  "traffic": path_bytes,
+                                  "frac_of_min_bytes": round(tb["total"] * units / (r["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "min_bytes_per_call": int(tb["total"] * units)},
+                         "kernels": kernels}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,7 +334,16 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the streaming / end-to-end / single-block legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU baseline sample length (all-core leg)")
     ap.add_argument("--tune", default="", help="engine tuning for experiments, e.g. mac_form=16,fwd_run=8")
+    ap.add_argument("--skip", default="", help="comma-separated extra legs to leave out: streaming,end_to_end,single_block,drop_in,configs")
+    ap.add_argument("--only-config", default="", choices=["", "cfg2", "cfg4"],
+                    help="run only this configuration's loop and print its `configs` entry (what tools/profile.sh profiles)")
+    ap.add_argument("--config-blocks", type=int, default=256, help="blocks per call of the cfg2 / cfg4 legs")
     args = ap.parse_args()
+    if args.only_config:
+        import torch  # noqa: F401
+        tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))} if args.tune else None
+        print(json.dumps({args.only_config: config_line(args.only_config, args.config_blocks, steps=min(args.steps, 300), tune=tune)}))
+        return
 
     import torch
     import folve_amd as fa
@@ -411,10 +554,11 @@ def main():
         roofline["measured_hbm"] = {"error": str(ex)}
 
     extras = world == 1 and not args.no_extras
+    skip = set(x for x in args.skip.split(",") if x)
     # ---- streaming form (one block per stream per call = SoundProcessor::Process granularity): here K2
     # really streams K spectra per block, so algorithmic and moved bytes coincide ----
     streaming = None
-    if extras:
+    if extras and "streaming" not in skip:
         st1 = [flt.open_stream(1) for _ in range(S)]
         plan1 = BatchPlan(st1, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [P] * S,
                           FE_DEVICE_PTRS | FE_ASYNC)
@@ -449,7 +593,7 @@ def main():
 
     # ---- end to end: the same batch from page-locked host buffers, PCIe inside the timed region ----
     end_to_end = None
-    if extras:
+    if extras and "end_to_end" not in skip:
         try:
             hin = [torch.empty(T * P, C).pin_memory() for _ in range(S)]
             hout = [torch.empty(T * P, C).pin_memory() for _ in range(S)]
@@ -476,7 +620,7 @@ def main():
 
     # ---- the drop-in call: one synchronous stereo block through fe_stream_process ----
     single = None
-    if extras:
+    if extras and "single_block" not in skip:
         try:
             L = fa.lib()
             nbytes = P * C * 4
@@ -515,7 +659,7 @@ def main():
     # ConvolveFileHandler does — a C++ host over include/folve_host.h (tools/dropin/dropin_threads.cpp, built by
     # __graft_entry__.build()), run as a child process; the same filter through the real loader (.conf + WAV) ----
     drop_in = None
-    if extras:
+    if extras and "drop_in" not in skip:
         try:
             import subprocess
             import tempfile
@@ -553,6 +697,16 @@ def main():
                        "usable_cpus": usable_cpus()[0], "runs": runs}
         except Exception as e:  # noqa: BLE001
             drop_in = {"error": repr(e)}
+
+    # ---- the other single-GPU configurations, each with its own roofline ----
+    configs = None
+    if extras and "configs" not in skip:
+        configs = {}
+        for name in OTHER_CONFIGS:
+            try:
+                configs[name] = config_line(name, args.config_blocks, dev=dev)
+            except Exception as e:  # noqa: BLE001
+                configs[name] = {"error": repr(e)}
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -602,6 +756,7 @@ def main():
             "end_to_end": end_to_end,
             "single_block": single,
             "drop_in_threads": drop_in,
+            "configs": configs,
             "cpu_baseline": cpu,
         }
         if world > 1:

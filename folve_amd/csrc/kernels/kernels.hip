@@ -166,7 +166,7 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
 // ---------------------------------------------------------------------------
 template <int LOG2P>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const StreamJob* __restrict__ jobs,
-                                                                      FilterDev f) {
+                                                                      FilterDev f, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     // the stage-B pass tables ride into LDS beside the PCM loads (visible after the barrier that
@@ -176,11 +176,12 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += G::NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
-    // grid (8 * channels, blocks / 8, streams): the channels of a block are dispatched together and — workgroup ids
-    // going round the 8 XCDs — land on ONE XCD, so the strided reads of the same interleaved frames meet in its L2
-    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
+    // xl: grid (8 * channels, blocks / 8, streams) — the channels of a block are dispatched together and, workgroup ids
+    // going round the 8 XCDs, land on ONE XCD, so the strided reads of the same interleaved frames meet in its L2.
+    // Calls of fewer than 8 blocks keep grid (blocks, channels, streams): that order would put them all on one XCD.
+    const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (b >= job.nblocks) return;
-    const int c = blockIdx.x >> 3;
+    const int c = xl ? blockIdx.x >> 3 : blockIdx.y;
     const int tid = threadIdx.x;
     const int cin = f.cin;
     const long long f0 = (long long)b * P;               // first frame of the block
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
 // samples in registers (only the lower half of z is data: 8 elements per thread and channel) and transforms one channel
 // after the other in the same LDS image.  grid (8 * pairs, blocks / 8, streams), as forward_kernel.
 template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f) {
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
@@ -236,9 +237,9 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(con
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
-    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
+    const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (b >= job.nblocks) return;
-    const int c0 = (blockIdx.x >> 3) * 2;
+    const int c0 = (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
     const int tid = threadIdx.x;
     const int cin = f.cin;
     const long long f0 = (long long)b * P;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256) void make_g_kernel(const float2* __restrict__ 
 template <int LOG2P>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const StreamJob* __restrict__ jobs,
                                                                       FilterDev f,
-                                                                      const float2* __restrict__ Y) {
+                                                                      const float2* __restrict__ Y, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
@@ -644,11 +645,11 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
-    // grid (8 * channels, blocks / 8, streams), as forward_kernel: the 4-byte stores of a block's channels into the
+    // xl: grid (8 * channels, blocks / 8, streams), as forward_kernel: the 4-byte stores of a block's channels into the
     // same interleaved frames meet in one XCD's L2 instead of reaching HBM as partial lines at different times
-    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
+    const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (b >= job.nblocks) return;
-    const int o = blockIdx.x >> 3;
+    const int o = xl ? blockIdx.x >> 3 : blockIdx.y;
     const int tid = threadIdx.x;
     const int cout = f.cout;
     const float2* __restrict__ y = Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P;
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
 // of the per-channel kernel, 8 of every 32 bytes of a line instead of 4).  grid (8 * pairs, blocks / 8, streams).
 template <int LOG2P>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
-                                                                             const float2* __restrict__ Y) {
+                                                                             const float2* __restrict__ Y, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
@@ -774,9 +775,9 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(con
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     const StreamJob job = jobs[blockIdx.z];
-    const int b = blockIdx.y * 8 + (blockIdx.x & 7);
+    const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (b >= job.nblocks) return;
-    const int o0 = (blockIdx.x >> 3) * 2;
+    const int o0 = (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
     const int tid = threadIdx.x;
     const int cout = f.cout;
     const float2* __restrict__ tw = f.tw;
@@ -1809,13 +1810,14 @@ struct FwdLaunch {
                 return hipGetLastError();
             }
         }
+        const int xl = max_blocks >= 8 ? 1 : 0;               // XCD-local order of a block's channels (see forward_kernel)
         if (tn.fft_form != 1 && pairs_ok && f.cin >= 4 && f.cin % 2 == 0) {   // many channels: a workgroup per channel pair
-            dim3 grid(8 * (f.cin / 2), (max_blocks + 7) / 8, njobs), block(WaveGeom<L>::NT);
-            hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, block, 0, st, jobs, f);
+            const dim3 grid = xl ? dim3(8 * (f.cin / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin / 2, njobs);
+            hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, xl);
             return hipGetLastError();
         }
-        dim3 grid(8 * f.cin, (max_blocks + 7) / 8, njobs), block(WaveGeom<L>::NT);
-        hipLaunchKernelGGL(forward_kernel<L>, grid, block, 0, st, jobs, f);
+        const dim3 grid = xl ? dim3(8 * f.cin, (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin, njobs);
+        hipLaunchKernelGGL(forward_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, xl);
         return hipGetLastError();
     }
 };
@@ -1846,13 +1848,14 @@ struct InvLaunch {
                 return hipGetLastError();
             }
         }
+        const int xl = max_blocks >= 8 ? 1 : 0;
         if (tn.fft_form != 1 && pairs_ok && f.cout >= 4 && f.cout % 2 == 0) {
-            dim3 grid(8 * (f.cout / 2), (max_blocks + 7) / 8, njobs), block(NT);
-            hipLaunchKernelGGL(inverse_chpair_kernel<L>, grid, block, 0, st, jobs, f, Y);
+            const dim3 grid = xl ? dim3(8 * (f.cout / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cout / 2, njobs);
+            hipLaunchKernelGGL(inverse_chpair_kernel<L>, grid, dim3(NT), 0, st, jobs, f, Y, xl);
             return hipGetLastError();
         }
-        dim3 grid(8 * f.cout, (max_blocks + 7) / 8, njobs), block(NT);
-        hipLaunchKernelGGL(inverse_kernel<L>, grid, block, 0, st, jobs, f, Y);
+        const dim3 grid = xl ? dim3(8 * f.cout, (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cout, njobs);
+        hipLaunchKernelGGL(inverse_kernel<L>, grid, dim3(NT), 0, st, jobs, f, Y, xl);
         return hipGetLastError();
     }
 };

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, S, T, K, C = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 summ = json.load(open(os.path.join(ROOT, "profiles", tag + "_summary.json")))
 ROLES = {
-    "T": {"forward": ("forward_walker_kernel",), "mac": ("mac_walk_kernel", "mac_slide_kernel"), "inverse": ("inverse_walker_kernel",)},
+    "T": {"forward": ("forward_walker_kernel", "forward_chpair_kernel", "forward_dual_kernel"),
+          "mac": ("mac_walk_kernel", "mac_slide_kernel"),
+          "inverse": ("inverse_walker_kernel", "inverse_chpair_kernel")},
     "1": {"forward": ("forward_kernel",), "mac": ("mac_kernel<1>",), "inverse": ("inverse_kernel",)},
 }
 
@@ -41,7 +43,7 @@ tj["_comment"] = ("HBM bytes per launch from rocprofv3 PMC passes over `python b
                   "(8-byte loads: every Y row once = 537 MB, counter 514 MB) and K1's spectra stores (8-byte: 537 MB, WRITE_SIZE "
                   "513 MB): exact to 1 % for 16-byte accesses, 4-5 % low for 8-byte ones.  avg_ns: kernel-trace averages of the "
                   "same launches; bench.py uses an entry only while its own HIP-event times agree with them (15 %).")
-for mode, blocks in (("T", T), ("1", 1)):
+for mode, blocks in ((("T", T), ("1", 1)) if "--run-ahead-only" not in sys.argv else (("T", T),)):
     entry = {"profile": tag, "bytes": {}, "avg_ns": {}, "read": {}, "write": {}, "kernels": {}}
     for role, names in ROLES[mode].items():
         key = pick_key(names)
