@@ -1035,6 +1035,7 @@ int fe_filter_commit(fe_filter* f) {
 }
 
 void fe_filter_retain(fe_filter* f) { if (f) f->refs.fetch_add(1); }
+int fe_filter_use_count(const fe_filter* f) { return f ? f->refs.load() : 0; }
 
 void fe_filter_release(fe_filter* f) {
     if (!f) return;

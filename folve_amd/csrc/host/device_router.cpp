@@ -2,6 +2,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 namespace folve {
 
@@ -88,22 +89,53 @@ int DeviceRouter::live_streams(int slot) const {
     return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)].live : 0;
 }
 
+// A cached filter that only the cache still holds (no stream uses it) and whose configuration file has changed or
+// is gone will never be asked for again under this mtime: let go of its spectra.
+void DeviceRouter::SweepLocked() {
+    for (auto it = filters_.begin(); it != filters_.end();) {
+        struct stat st;
+        const bool current = stat(it->first.first.c_str(), &st) == 0 && st.st_mtime == it->second.mtime;
+        if (!current && fe_filter_use_count(it->second.filter) == 1) {
+            fe_filter_release(it->second.filter);
+            it = filters_.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_file, time_t mtime, int samplerate,
                                    int channels, ZitaConfig* out_cfg) {
-    // Serialised like the reference serialises Create() (sound-processor.cc:43).
-    std::lock_guard<std::mutex> lk(mu_);
     const std::pair<std::string, fe_engine*> key(config_file, engine);
-    auto it = filters_.find(key);
-    if (it != filters_.end()) {
-        if (it->second.mtime == mtime) {
-            *out_cfg = it->second.cfg;
-            out_cfg->config_file = NULL;
-            fe_filter_retain(it->second.filter);
-            return it->second.filter;
+    {
+        // The reference serialises Create() as a whole (sound-processor.cc:43); here only the bookkeeping is
+        // serialised, and two threads never build the same (configuration, GPU) at once.
+        std::unique_lock<std::mutex> lk(mu_);
+        SweepLocked();
+        for (;;) {
+            auto it = filters_.find(key);
+            if (it != filters_.end()) {
+                if (it->second.mtime == mtime) {
+                    *out_cfg = it->second.cfg;
+                    out_cfg->config_file = NULL;
+                    fe_filter_retain(it->second.filter);
+                    return it->second.filter;
+                }
+                fe_filter_release(it->second.filter);    // configuration file was touched: rebuild
+                filters_.erase(it);
+            }
+            if (!building_.count(key)) break;
+            built_.wait(lk);                             // somebody is building this very filter: take theirs
         }
-        fe_filter_release(it->second.filter);    // configuration file was touched: rebuild
-        filters_.erase(it);
+        building_.insert(key);
     }
+    struct Done {                                        // whatever happens below: the key is no longer being built
+        DeviceRouter* r; const std::pair<std::string, fe_engine*>& key;
+        ~Done() {
+            { std::lock_guard<std::mutex> lk(r->mu_); r->building_.erase(key); }
+            r->built_.notify_all();
+        }
+    } done{this, key};
     ZitaConfig zita;
     memset(&zita, 0, sizeof(zita));
     zita.engine = engine;
@@ -122,7 +154,10 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
         return NULL;
     }
     zita.config_file = NULL;
-    filters_[key] = CachedFilter{zita.filter, zita, mtime};
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        filters_[key] = CachedFilter{zita.filter, zita, mtime};
+    }
     *out_cfg = zita;
     fe_filter_retain(zita.filter);
     return zita.filter;

@@ -6,12 +6,18 @@
 // goes to the device with the fewest live streams.  Committed filters are cached
 // per (config path, mtime, slot) so that all streams of one configuration on a
 // GPU share a single set of spectra — which is also what lets them be batched.
+// Parsing a configuration and transforming its taps (hundreds of milliseconds for a
+// long impulse response) happens OUTSIDE the router's lock: the key is marked as
+// being built, other threads asking for the same key wait for it, and everybody
+// else — PickEngine / StreamClosed for any GPU, other configurations — carries on.
 #pragma once
 
 #include <time.h>
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -46,7 +52,10 @@ public:
 private:
     struct Slot { int device; fe_engine* engine; int live; };
     struct CachedFilter { fe_filter* filter; ZitaConfig cfg; time_t mtime; };
+    void SweepLocked();                        // drop cached filters nobody uses whose configuration changed or vanished
     mutable std::mutex mu_;
+    std::condition_variable built_;            // a filter that was being built has been cached (or has failed)
+    std::set<std::pair<std::string, fe_engine*>> building_;   // keys whose filter some thread is parsing / transforming right now
     std::vector<Slot> slots_;
     std::map<std::pair<std::string, fe_engine*>, CachedFilter> filters_;   // (config path, engine of a slot) -> filter
 };

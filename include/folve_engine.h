@@ -94,6 +94,7 @@ int fe_filter_commit(fe_filter *f);
 /* Reference counting: create returns 1 reference; each open stream holds one. */
 void fe_filter_retain(fe_filter *f);
 void fe_filter_release(fe_filter *f);
+int fe_filter_use_count(const fe_filter *f);      /* references held right now (a cache that sees 1 is the only holder) */
 int fe_filter_inputs(const fe_filter *f);
 int fe_filter_outputs(const fe_filter *f);
 int fe_filter_block_size(const fe_filter *f);     /* P = fragm */

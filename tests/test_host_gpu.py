@@ -373,3 +373,61 @@ def test_single_block_latency_and_zero_copy(oracle, tmp_path):
     full = oracle.linear_convolution_f64(x, hs, 2)
     assert oracle.rms(np.concatenate([y, y2]) - full) <= TOL
     assert dt < 500e-6, dt                                           # per block, Python loop included
+
+
+def test_router_builds_filters_outside_its_lock_and_sweeps_stale_ones(oracle, tmp_path):
+    """DeviceRouter::GetFilter: many threads opening the SAME new configuration get one shared filter (one thread builds
+    it, the others wait for that key only); a configuration that was touched while nobody uses it is dropped from the
+    cache the next time any filter is asked for."""
+    d1, hs = make_santalucia_shaped_dir(tmp_path / "a")
+    d2 = make_echo_filter_dir(tmp_path / "b")
+    c1, c2 = os.path.join(d1, "filter-44100.conf"), os.path.join(d2, "filter-44100.conf")
+    base = H._L().fh_router_cached_filters()
+    procs = [None] * 10
+
+    def open_one(i):
+        procs[i] = H.SoundProcessor.create(c1 if i % 5 else c2, 44100, 2)
+
+    th = [threading.Thread(target=open_one, args=(i,)) for i in range(len(procs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(p is not None for p in procs)
+    assert H._L().fh_router_cached_filters() == base + 2            # one per configuration, however many threads asked
+    x = seeded_input(8, 3 * 8192 + 5, 2)
+    assert oracle.rms(procs[1].run(x) - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+    for p in procs:
+        p.close()
+    time.sleep(1.1)
+    os.utime(c1, None)                                               # c1's cached filter is stale and unused now
+    again = H.SoundProcessor.create(c2, 44100, 2)                    # any GetFilter sweeps
+    assert again is not None
+    assert H._L().fh_router_cached_filters() == base + 1
+    fresh = H.SoundProcessor.create(c1, 44100, 2)                    # and the touched configuration is rebuilt on demand
+    assert fresh is not None and H._L().fh_router_cached_filters() == base + 2
+    assert oracle.rms(fresh.run(x) - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+
+
+def test_a_blocks_bits_across_batch_sizes(oracle, tmp_path):
+    """What the combiner may promise about bits (batch_scheduler.h): one-block requests that travel in batches of at
+    most 64 blocks use the latency kernels a lone block uses — bit-identical; larger batches switch K1/K3 (65 - 255 blocks:
+    per-channel kernels with table twiddles; >= 256: walkers) and K2 forms, which differ in rounding only."""
+    import folve_amd as fa
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    st, flt, _ = H.config_load(os.path.join(d, "filter-44100.conf"), 44100, 2, engine=fa.Engine(0))
+    assert st == 0
+    flt.commit()
+    P = flt.block_size
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (P, 2)).astype(np.float32)
+
+    def first_of(n):
+        streams = [flt.open_stream(1) for _ in range(n)]
+        xs = [x] + [rng.uniform(-1, 1, (P, 2)).astype(np.float32) for _ in range(n - 1)]
+        return fa.batch_process(streams, xs)[0]
+
+    lone = first_of(1)
+    assert np.array_equal(first_of(40), lone)
+    for n in (100, 300):
+        y = first_of(n)
+        assert oracle.rms(y - lone) <= 2e-6
+    assert oracle.rms(lone - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
