@@ -689,12 +689,29 @@ def main():
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 runs.append(json.loads(line[-1]) if line else {"threads": nt, "combiner": bool(comb), "run_ahead": ra,
                                                                "error": "rc %d" % r.returncode})
+            # The multi-GPU path folve itself would run: ONE process, ProcessorPool -> DeviceRouter spreading the open files
+            # over every visible GPU (least-loaded, sticky), each file thread and its page-locked ring placed on its GPU's
+            # NUMA node.  Only when more than one GPU is visible to this process.
+            ndev = fa.lib().fe_device_count()
+            multi = None
+            if ndev > 1:
+                per_gpu = 64
+                nt = min(per_gpu * ndev, 512)
+                env = dict(os.environ)
+                env.pop("FOLVE_AMD_DEVICES", None)
+                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), "2048", "1", "json", "run_ahead=32", "pin=1"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, env=env)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                multi = json.loads(line[-1]) if line else {"error": "rc %d" % r.returncode}
+                multi["what"] = ("one process, %d file threads over %d GPUs through folve::DeviceRouter (streams to the least-loaded "
+                                 "GPU, one combiner and one engine per GPU, no collective), run-ahead 32, threads and rings "
+                                 "NUMA-placed next to their GPU" % (nt, ndev))
             drop_in = {"what": "N host threads, each a folve::SoundProcessor (page-locked ring, per-GPU combiner) pulling 8192-frame "
                                "stereo blocks as ConvolveFileHandler::AddMoreSoundData does: FillBuffer -> WriteProcessed over "
                                "sf_readf_float / sf_writef_float-shaped callbacks that copy every block in and out, K = %d; "
                                "run_ahead = blocks a processor reads ahead of its reader (1 = the reference's one block per "
                                "Process() call); child process, tools/dropin/dropin_threads.cpp" % K,
-                       "usable_cpus": usable_cpus()[0], "runs": runs}
+                       "usable_cpus": usable_cpus()[0], "runs": runs, "multi_gpu": multi}
         except Exception as e:  # noqa: BLE001
             drop_in = {"error": repr(e)}
 
@@ -713,26 +730,43 @@ def main():
         from oracle import oracle as O      # CPU restatement: the baseline being reported, not the product
         native = O.native_bench_lib() is not None
         cores, host_cpus, cores_why = usable_cpus()
-        # a short probe runs ~2.5x faster per block than the steady state (cold DRAM working set of
-        # 8 MB per stream builds up), so size the sample from a 16-block probe
-        tprobe = O.bench_streams(cores, 16, cores, C, C, size, 3, native=native) / 16.0    # seconds per block round
-        nblocks = int(max(8, min(65536, args.cpu_seconds / max(tprobe * 1.5, 1e-4))))
-        tcpu = O.bench_streams(cores, nblocks, cores, C, C, size, 3, native=native)
-        tp1 = O.bench_streams(1, 64, 1, C, C, size, 3, native=native) / 64.0               # one stream alone is cache-resident: its own probe
-        nb1 = int(max(64, min(65536, 0.4 * args.cpu_seconds / max(tp1, 1e-6))))
-        t1c = O.bench_streams(1, nb1, 1, C, C, size, 3, native=native)
         zita = bool(ctypes.util.find_library("zita-convolver")) and any(
             os.path.exists(os.path.join(d, "zita-convolver.h")) for d in ("/usr/include", "/usr/local/include"))
-        cpu = {"value": round(cores * nblocks * P * C / tcpu / 1e6, 2), "unit": "Msamples/s", "cores": cores,
+
+        def timed(fn, budget):
+            """(all-core rate, sample text, one-core rate, sample text) of one CPU engine, sized to `budget` seconds."""
+            # a short probe runs ~2.5x faster per block than the steady state (cold DRAM working set of
+            # 8 MB per stream builds up), so size the sample from a 16-block probe
+            tprobe = fn(cores, 16, cores) / 16.0                                  # seconds per block round
+            nblocks = int(max(8, min(65536, budget / max(tprobe * 1.5, 1e-4))))
+            tall = fn(cores, nblocks, cores)
+            tp1 = fn(1, 64, 1) / 64.0                                             # one stream alone is cache-resident: its own probe
+            nb1 = int(max(64, min(65536, 0.4 * budget / max(tp1, 1e-6))))
+            t1 = fn(1, nb1, 1)
+            return (cores * nblocks * P * C / tall / 1e6,
+                    "%d streams x %d blocks x %d ch, %d taps, one convolver per stream, %d threads, %.1f s" % (cores, nblocks, C, size, cores, tall),
+                    nb1 * P * C / t1 / 1e6,
+                    "1 stream x %d blocks, 1 thread, %.1f s (one stream's 8 MB of state stays in cache)" % (nb1, t1))
+
+        # the vectorised stand-in (oracle/fastcpu.c: split-complex radix-4 Stockham FFT, FMA multiply-accumulate) is the
+        # figure to compare with; the scalar parity oracle is timed beside it
+        fv, fs, f1, f1s = timed(lambda ns, nb, nt: O.fast_bench_streams(ns, nb, nt, C, size, 3, native=native), 0.6 * args.cpu_seconds)
+        sv, ss, s1, s1s = timed(lambda ns, nb, nt: O.bench_streams(ns, nb, nt, C, C, size, 3, native=native), 0.4 * args.cpu_seconds)
+        cpu = {"value": round(fv, 2), "unit": "Msamples/s", "cores": cores,
                "cores_note": "%d threads = the CPUs this process may use (%s); the host has %d" % (cores, cores_why, host_cpus),
                "kind": "port",
-               "what": "CPU restatement of zita-convolver's algorithm (zita-convolver/FFTW unavailable offline); "
-                       "scalar radix-2 FFT, so a pessimistic stand-in for zita + FFTW: do not quote the ratio",
+               "what": "CPU restatement of zita-convolver's algorithm as folve configures it (one level, partition 8192, one engine "
+                       "per open file: /root/reference/zita-fconfig.cc:74-81), vectorised: split-complex radix-4 Stockham real FFT and "
+                       "an FMA multiply-accumulate over structure-of-arrays spectra (oracle/fastcpu.c).  zita-convolver / FFTW are "
+                       "unavailable offline: this is a stand-in, not zita.  Its time is the multiply-accumulate streaming K spectra "
+                       "of the stream and of the filter per block (4 MB per channel and block) through the cache hierarchy.",
                "build": "-O3 -march=native on this box" if native else "-O3 -march=x86-64-v3 (prebuilt)",
-               "sample": "%d streams x %d blocks x %d ch, %d taps, one Convproc per stream, %d threads, %.1f s"
-                         % (cores, nblocks, C, size, cores, tcpu),
-               "one_core": {"value": round(nb1 * P * C / t1c / 1e6, 2), "unit": "Msamples/s", "cores": 1,
-                            "sample": "1 stream x %d blocks, 1 thread, %.1f s (one stream's 8 MB of state stays in cache)" % (nb1, t1c)},
+               "sample": fs,
+               "one_core": {"value": round(f1, 2), "unit": "Msamples/s", "cores": 1, "sample": f1s},
+               "scalar_oracle": {"value": round(sv, 2), "unit": "Msamples/s", "cores": cores, "sample": ss,
+                                 "one_core": {"value": round(s1, 2), "sample": s1s},
+                                 "what": "the parity oracle itself (oracle_convproc.c + oracle_fft.c: scalar radix-2 FFT, written to be "
+                                         "read): a pessimistic figure, kept for continuity with rounds 1 - 2"},
                "zita_convolver_on_this_box": zita}
 
     if rank == 0:
@@ -756,6 +790,7 @@ def main():
             "end_to_end": end_to_end,
             "single_block": single,
             "drop_in_threads": drop_in,
+            "drop_in_threads_multi_gpu": (drop_in or {}).get("multi_gpu") if isinstance(drop_in, dict) else None,
             "configs": configs,
             "cpu_baseline": cpu,
         }

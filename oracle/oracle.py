@@ -64,6 +64,8 @@ def lib():
     L.oc_sp_run.argtypes = [vp, vp, C.c_long, vp]; L.oc_sp_run.restype = C.c_long
     L.oc_bench_streams.argtypes = [ci, ci, ci, ci, ci, ci, C.c_uint]; L.oc_bench_streams.restype = C.c_double
     L.oc_wav_load.argtypes = [C.c_char_p, vp]
+    L.fc_run.argtypes = [ci, ci, ci, vp, vp, C.c_long, vp]; L.fc_run.restype = ci
+    L.fc_bench_streams.argtypes = [ci] * 6 + [C.c_uint]; L.fc_bench_streams.restype = C.c_double
     _LIB = L
     return L
 
@@ -207,6 +209,8 @@ def native_bench_lib():
             L = C.CDLL(so)
             L.oc_bench_streams.argtypes = [C.c_int] * 6 + [C.c_uint]
             L.oc_bench_streams.restype = C.c_double
+            L.fc_bench_streams.argtypes = [C.c_int] * 6 + [C.c_uint]
+            L.fc_bench_streams.restype = C.c_double
             _NATIVE = L
         except Exception:
             _NATIVE = False
@@ -216,6 +220,23 @@ def native_bench_lib():
 def bench_streams(nstreams, nblocks, nthreads, ninp=2, nout=2, size=262144, seed=3, native=False):
     L = (native_bench_lib() if native else None) or lib()
     return L.oc_bench_streams(nstreams, nblocks, nthreads, ninp, nout, size, seed)
+
+
+def fast_bench_streams(nstreams, nblocks, nthreads, nch=2, size=262144, seed=3, native=False):
+    """Seconds for the vectorised stand-in (oracle/fastcpu.c): same algorithm and shape as bench_streams."""
+    L = (native_bench_lib() if native else None) or lib()
+    return L.fc_bench_streams(nstreams, nblocks, nthreads, nch, size, fragm_for_size(size), seed)
+
+
+def fast_run(x, taps, size=None):
+    """x [frames (a multiple of the block), nch] through oracle/fastcpu.c with `taps` on every diagonal path."""
+    x = np.ascontiguousarray(x, np.float32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    size = size or len(taps)
+    y = np.zeros_like(x)
+    rc = lib().fc_run(x.shape[1], size, fragm_for_size(size), _fptr(taps), _fptr(x), x.shape[0], _fptr(y))
+    assert rc == 0
+    return y
 
 
 # --------------------------------------------------------------------------

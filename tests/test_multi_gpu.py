@@ -48,3 +48,21 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]   # gpu = stream mod N
     assert out["parity_rms"] is not None and out["parity_rms"] <= 1e-5
     assert out["value"] > 0
+
+
+def test_harness_over_two_router_slots_with_numa_placement(tmp_path):
+    """bench.py's drop_in_threads_multi_gpu leg on a one-GPU box: the C++ harness with two router slots (both device 0),
+    run-ahead on, NUMA placement on (a no-op where sysfs says nothing): the streams split evenly, both engines work."""
+    exe = os.path.join(ROOT, "tools", "dropin", "dropin_threads")
+    if not os.path.exists(exe):
+        pytest.skip("tools/dropin/dropin_threads not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dropin"))
+    import make_conf
+    conf = make_conf.write(str(tmp_path), 65536)
+    env = dict(os.environ, FOLVE_AMD_DEVICES="0,0")
+    r = subprocess.run([exe, conf, "8", "256", "1", "json", "run_ahead=8", "pin=1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["threads"] == 8 and out["run_ahead"] == 8 and out["numa_pin"]
+    assert out["gpus"]["0"]["streams"] == 8                                    # (two slots, one physical device)
+    assert out["blocks_per_s"] > 0 and out["requests"] < 8 * 256              # blocks travelled in chunks

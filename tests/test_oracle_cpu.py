@@ -161,6 +161,7 @@ def test_committed_traffic_table_is_consistent():
     family = {"forward": ("forward_",), "mac": ("mac_",), "inverse": ("inverse_",)}
     shapes = [k for k in tj if k != "_comment"]
     assert "S64_T256_K32_C2" in shapes                          # bench.py's default shape
+    assert "S1_T256_K25_C2" in shapes and "S1_T256_K64_C8" in shapes       # its cfg2 / cfg4 legs
     for key in shapes:
         e = tj[key]
         assert e["profile"] and os.path.exists(os.path.join(root, "profiles", e["profile"] + "_summary.json")), key
@@ -170,9 +171,30 @@ def test_committed_traffic_table_is_consistent():
             assert e["kernels"][role].startswith(prefixes), (key, role, e["kernels"][role])
             assert abs(e["read"][role] + e["write"][role] - e["bytes"][role]) <= 2          # (each rounded to an integer)
         if blocks > 1:                                           # run-ahead launches: the fast forms
-            assert e["kernels"]["forward"].startswith("forward_walker_kernel")
+            channels = int(key.split("_")[3][1:])
+            fwd, inv = ("forward_walker_kernel", "inverse_walker_kernel") if channels <= 2 else ("forward_chpair_kernel", "inverse_chpair_kernel")
+            assert e["kernels"]["forward"].startswith(fwd)
             assert e["kernels"]["mac"].startswith(("mac_walk_kernel", "mac_slide_kernel"))
-            assert e["kernels"]["inverse"].startswith("inverse_walker_kernel")
+            assert e["kernels"]["inverse"].startswith(inv)
             # bytes / time: a physically possible HBM rate
             for role in family:
                 assert e["bytes"][role] / e["avg_ns"][role] < 8000.0, (key, role)      # GB/s
+
+
+def test_vectorised_cpu_stand_in_matches_the_scalar_oracle(oracle):
+    """oracle/fastcpu.c (bench.py's cpu_baseline: split-complex radix-4 Stockham FFT, FMA MAC) computes the same
+    convolution as the scalar parity oracle and the float64 ground truth, for block sizes 8192, 4096 and 1024
+    (log2 of the complex length odd and even: with and without the closing radix-2 stage)."""
+    rng = np.random.default_rng(21)
+    for size in (20000, 5000, 700):
+        P = oracle.fragm_for_size(size)
+        taps = (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32)
+        x = rng.uniform(-1, 1, (4 * P, 2)).astype(np.float32)
+        y = oracle.fast_run(x, taps)
+        conv = oracle.Convproc(2, 2, size)
+        for c in range(2):
+            conv.impdata_create(c, c, taps, 0)
+        yo = oracle.SoundProcessor.wrap(conv).run(x)
+        ref = oracle.linear_convolution_f64(x, {(0, 0): taps, (1, 1): taps}, 2)
+        assert oracle.rms(y - yo) <= 1e-6 and oracle.rms(y - ref) <= 1e-6, size
+    assert oracle.fast_bench_streams(2, 2, 2, 2, 20000) > 0
