@@ -681,7 +681,7 @@ def main():
                     f.write("/impulse/read %d %d 2e-3 0 0 0 %d ir.wav\n" % (c + 1, c + 1, c + 1))
             runs = []
             # (threads, combiner, run-ahead depth in blocks): depth 1 is the reference's one block per Process() call
-            for nt, comb, ra in ((1, 1, 1), (1, 1, 32), (16, 1, 32), (64, 1, 1), (64, 1, 32), (64, 1, 64), (64, 0, 1)):
+            for nt, comb, ra in ((1, 1, 1), (1, 1, 64), (16, 1, 64), (64, 1, 1), (64, 1, 32), (64, 1, 64), (64, 1, 128), (64, 0, 1)):
                 nblk = 300 if ra == 1 else (20000 if nt == 1 else 4096 if nt <= 16 else 2048)
                 r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), str(nblk), str(comb), "json",
                                     "run_ahead=%d" % ra],
@@ -699,12 +699,12 @@ def main():
                 nt = min(per_gpu * ndev, 512)
                 env = dict(os.environ)
                 env.pop("FOLVE_AMD_DEVICES", None)
-                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), "2048", "1", "json", "run_ahead=32", "pin=1"],
+                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), "2048", "1", "json", "run_ahead=64", "pin=1"],
                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, env=env)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 multi = json.loads(line[-1]) if line else {"error": "rc %d" % r.returncode}
                 multi["what"] = ("one process, %d file threads over %d GPUs through folve::DeviceRouter (streams to the least-loaded "
-                                 "GPU, one combiner and one engine per GPU, no collective), run-ahead 32, threads and rings "
+                                 "GPU, one combiner and one engine per GPU, no collective), run-ahead 64, threads and rings "
                                  "NUMA-placed next to their GPU" % (nt, ndev))
             drop_in = {"what": "N host threads, each a folve::SoundProcessor (page-locked ring, per-GPU combiner) pulling 8192-frame "
                                "stereo blocks as ConvolveFileHandler::AddMoreSoundData does: FillBuffer -> WriteProcessed over "

@@ -92,6 +92,10 @@ struct fe_engine {
     bool in_resident = false;            // ... its input has been staged into device memory by DMA (run_duplex)
     float* dx_stage[2] = {};             // run_duplex: input staging, alternating between consecutive batches
     size_t dx_stage_bytes[2] = {};
+    float* dx_stage_out[2] = {};         // ... and output staging when the results leave by DMA too (FE_TUNE_DUPLEX_OUT = 2)
+    size_t dx_stage_out_bytes[2] = {};
+    hipEvent_t dx_k3[16] = {};           // "K3 of chunk c has finished"
+    int duplex_out = 0;                  // 0 / 2: K3 -> device staging -> DMA out; 1: K3 stores into the callers' buffers
     hipEvent_t dx_free[2] = {};          // the batch that last used dx_stage[i] has finished
     bool dx_free_pending[2] = {};
     int dx_parity = 0;
@@ -431,15 +435,17 @@ int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* c
 }
 
 // A large zero-copy call (the combined run-ahead chunks of many files: tens of megabytes of PCM each way) as a
-// duplex pipeline.  Measured on MI355X (profiles/r03_dropin_*): kernels WRITE page-locked host memory at 43 - 50 GB/s,
-// but READ it at 28 - 35 GB/s only (64-byte read requests, a bounded number in flight), where the DMA engines read at
-// the bus rate.  So the streams are cut into chunks; every chunk's PCM is copied into device memory by the copy
-// stream (inbound, DMA), its K1/K2 run from HBM and its K3 writes the results straight into the callers' buffers
-// (outbound, kernel stores).  Chunks alternate between the two lanes, so the K3 of chunk c runs beside the K1/K2 of
-// chunk c + 1 and beside the copies of the chunks after it: both directions of the bus are busy for the whole call,
-// whatever the host threads' timing is.  The staging buffer alternates between consecutive batches, so the next
-// batch's copies start while this one still computes.  At the end `lane` (the one the caller records its completion
-// event on) waits for the other.
+// duplex pipeline.  Measured on MI355X (profiles/r03*_dropin_*): kernels READ page-locked host memory at 28 - 35 GB/s
+// only (64-byte read requests, a bounded number in flight) and WRITE it at 41 GB/s while they hold the CUs; the DMA
+// engines move 45 - 50 GB/s each way at once and leave the CUs alone (64 file threads: 6.0 Gsamples/s with kernel reads
+// and writes, 8.2 with DMA in and kernel stores out, 9.0 - 9.5 with DMA both ways).  So the streams are cut into chunks;
+// every chunk's PCM is copied into device memory by one copy stream (inbound), its K1/K2/K3 run from and to HBM on one
+// of the two lanes, and its results are copied into the callers' buffers by another copy stream (outbound): chunk
+// c + 1 rides in and chunk c - 1 rides out while chunk c computes — both directions of the bus are busy for the whole
+// call, whatever the host threads' timing is.  The staging buffers alternate between consecutive batches, so the next
+// batch's copies start while this one still computes.  (FE_TUNE_DUPLEX_OUT = 1: K3 stores straight into the callers'
+// buffers instead of the outbound copies.)  At the end `lane` (the one the caller records its completion event on)
+// waits for the other lane and for the last copy out.
 constexpr int kDuplexChunks = 16;
 struct DuplexPlan {
     int nc = 0;
@@ -460,12 +466,15 @@ void plan_duplex(fe_stream* const* streams, int n, const long long* nframes, int
     p->first[++p->nc] = n;
 }
 int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int n, const float* const* host_in,
-               const long long* nframes, int lane, const DuplexPlan& p) {
+               float* const* host_out, const long long* nframes, int lane, const DuplexPlan& p) {
+    const bool dma_out = e->duplex_out != 1;
     if (!e->dx_ev[0]) {
         for (int i = 0; i < kDuplexChunks; ++i) HIP_TRY(hipEventCreateWithFlags(&e->dx_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < kDuplexChunks; ++i) HIP_TRY(hipEventCreateWithFlags(&e->dx_k3[i], hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&e->dx_free[i], hipEventDisableTiming));
     }
     if (!e->cp_in) HIP_TRY(hipStreamCreateWithFlags(&e->cp_in, hipStreamNonBlocking));
+    if (dma_out && !e->cp_out) HIP_TRY(hipStreamCreateWithFlags(&e->cp_out, hipStreamNonBlocking));
     const int par = e->dx_parity;
     e->dx_parity ^= 1;
     // the batch before last used this staging buffer: it has long finished (at most two batches are in flight)
@@ -486,6 +495,26 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         HIP_TRY(hipMalloc((void**)&e->dx_stage[par], need + need / 4));
         e->dx_stage_bytes[par] = need + need / 4;
     }
+    size_t need_out = 0;
+    std::vector<size_t> off_out((size_t)n);
+    if (dma_out) {
+        for (int i = 0; i < n; ++i) {
+            off_out[(size_t)i] = need_out;
+            need_out += (((size_t)nframes[i] * streams[i]->f->nout + 3) & ~(size_t)3) * sizeof(float);
+        }
+        if (e->dx_stage_out_bytes[par] < need_out) {
+            if (e->dx_stage_out[par]) HIP_TRY(hipFree(e->dx_stage_out[par]));
+            e->dx_stage_out[par] = nullptr;
+            e->dx_stage_out_bytes[par] = 0;
+            HIP_TRY(hipMalloc((void**)&e->dx_stage_out[par], need_out + need_out / 4));
+            e->dx_stage_out_bytes[par] = need_out + need_out / 4;
+        }
+    }
+    struct HostOutScope {                // with the results leaving by DMA the kernels see device memory on both sides
+        fe_engine* e; bool was;
+        HostOutScope(fe_engine* e_, bool off) : e(e_), was(e_->host_io) { if (off) e->host_io = false; }
+        ~HostOutScope() { e->host_io = was; }
+    } host_out_scope(e, dma_out);
     struct ResidentScope {
         fe_engine* e;
         explicit ResidentScope(fe_engine* e_) : e(e_) { e->in_resident = true; }
@@ -500,6 +529,7 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
             float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(e->dx_stage[par]) + off[(size_t)i]);
             if (bytes) HIP_TRY(hipMemcpyAsync(dst, host_in[i], bytes, hipMemcpyHostToDevice, e->cp_in));
             all[(size_t)i].in = dst;
+            if (dma_out) all[(size_t)i].out = reinterpret_cast<float*>(reinterpret_cast<char*>(e->dx_stage_out[par]) + off_out[(size_t)i]);
         }
         HIP_TRY(hipEventRecord(e->dx_ev[c], e->cp_in));
         HIP_TRY(hipStreamWaitEvent(e->lanes[l].st, e->dx_ev[c], 0));
@@ -507,8 +537,22 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         if (rc) {
             (void)hipStreamSynchronize(e->lanes[l ^ 1].st);     // earlier chunks still write into the callers' buffers
             (void)hipStreamSynchronize(e->cp_in);
+            if (dma_out) (void)hipStreamSynchronize(e->cp_out);
             return rc;
         }
+        if (dma_out) {
+            HIP_TRY(hipEventRecord(e->dx_k3[c], e->lanes[l].st));
+            HIP_TRY(hipStreamWaitEvent(e->cp_out, e->dx_k3[c], 0));
+            for (int i = first[c]; i < first[c + 1]; ++i) {
+                const size_t bytes = (size_t)nframes[i] * streams[i]->f->nout * sizeof(float);
+                const char* src = reinterpret_cast<const char*>(e->dx_stage_out[par]) + off_out[(size_t)i];
+                if (bytes) HIP_TRY(hipMemcpyAsync(host_out[i], src, bytes, hipMemcpyDeviceToHost, e->cp_out));
+            }
+        }
+    }
+    if (dma_out) {                       // the caller's completion event (recorded on `lane`) must follow the last copy out
+        HIP_TRY(hipEventRecord(e->dx_k3[0], e->cp_out));
+        HIP_TRY(hipStreamWaitEvent(e->lanes[lane].st, e->dx_k3[0], 0));
     }
     const int other = lane ^ 1;
     HIP_TRY(hipEventRecord(e->lanes[other].xev, e->lanes[other].st));
@@ -551,6 +595,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     std::vector<float*> zc_out;
     bool zero_copy = false;
     const float* const* host_in = in;    // the callers' own pointers (run_duplex copies from them)
+    float* const* host_out = out;
     if (!device_ptrs && n > 0) {
         bool all_bound = true;
         for (int i = 0; i < n && all_bound; ++i) {
@@ -665,7 +710,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
                 if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, st));
             }
         }
-        int rc = duplex ? run_duplex(e, streams, all, n, host_in, nframes, lane, dplan) : run_groups(e, streams, all, 0, n, lane);
+        int rc = duplex ? run_duplex(e, streams, all, n, host_in, host_out, nframes, lane, dplan) : run_groups(e, streams, all, 0, n, lane);
         if (rc) return rc;
         if (!device_ptrs) {
             for (int i = 0; i < n; ++i) {
@@ -816,9 +861,11 @@ static void engine_release(fe_engine* e) {
         if (e->ev_k[i]) (void)hipEventDestroy(e->ev_k[i]);
     }
     for (hipEvent_t ev : e->dx_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->dx_k3) if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
         if (e->dx_free[i]) (void)hipEventDestroy(e->dx_free[i]);
         if (e->dx_stage[i]) (void)hipFree(e->dx_stage[i]);
+        if (e->dx_stage_out[i]) (void)hipFree(e->dx_stage_out[i]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -1390,6 +1437,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
         case FE_TUNE_WALK_TILES:
             if (value < 0 || value > 64) return fail(FE_ERR_PARAM, "time tiles must be 0 .. 64");
             e->tuning.walk_tiles = value;
+            return FE_OK;
+        case FE_TUNE_DUPLEX_OUT:
+            if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "duplex out must be 0, 1 or 2");
+            e->duplex_out = value;
             return FE_OK;
         case FE_TUNE_LANES:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "lanes must be 0 (automatic), 1 or 2");

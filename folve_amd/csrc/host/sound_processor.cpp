@@ -33,6 +33,9 @@ static time_t GetModificationTime(const std::string& filename) {
 namespace {
 std::atomic<int> g_run_ahead{-1};          // -1: not decided yet (environment)
 const int kMaxRunAhead = 1024;
+// 64 blocks = 12 s of 44.1 kHz audio per chunk: 8 MB of page-locked ring and 12.6 MB of delay line per open stereo file
+// at 256 k taps.  Measured with 64 file threads on one MI355X: depth 8: 5.5, 32: 8.0, 64: 9.0, 128: 9.2 Gsamples/s.
+const int kDefaultRunAhead = 64;
 }  // namespace
 
 void SoundProcessor::SetRunAhead(int blocks) { g_run_ahead.store(std::max(1, std::min(blocks, kMaxRunAhead))); }
@@ -41,7 +44,7 @@ int SoundProcessor::RunAhead() {
     int v = g_run_ahead.load();
     if (v < 0) {
         const char* env = getenv("FOLVE_AMD_RUN_AHEAD");
-        v = env ? std::max(1, std::min(atoi(env), kMaxRunAhead)) : 32;
+        v = env ? std::max(1, std::min(atoi(env), kMaxRunAhead)) : kDefaultRunAhead;
         g_run_ahead.store(v);
     }
     return v;

@@ -60,7 +60,7 @@ public:
     // Same, on a given engine (used by ProcessorPool's sharder).
     static SoundProcessor* CreateOn(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
     // Blocks a processor may read ahead of its reader (1 = off: one block per engine call, the reference's
-    // pattern).  Applies to processors created afterwards.  Default 32, or FOLVE_AMD_RUN_AHEAD.
+    // pattern).  Applies to processors created afterwards.  Default 64, or FOLVE_AMD_RUN_AHEAD.
     static void SetRunAhead(int blocks);
     static int RunAhead();
 private:

@@ -225,6 +225,9 @@ def batching_stats():
     return dict(zip(("requests", "blocks", "batches", "largest", "overlapped"), [x.value for x in v]))
 
 
+DEFAULT_RUN_AHEAD = 64
+
+
 def set_run_ahead(blocks):
     """Run-ahead depth (blocks) of SoundProcessors created from now on; 1 = off (folve::SoundProcessor::SetRunAhead)."""
     _L().fh_run_ahead_set(int(blocks))

@@ -47,7 +47,7 @@ typedef int (*fh_read_fn)(void *user, float *dst, int frames);
 typedef int (*fh_write_fn)(void *user, const float *src, int frames);
 int fh_processor_fill_buffer_from(fh_processor *p, fh_read_fn read, void *user);
 void fh_processor_write_processed_to(fh_processor *p, fh_write_fn write, void *user, int sample_count);
-/* Run-ahead depth in blocks for processors created from now on (1 = off; default 32 or FOLVE_AMD_RUN_AHEAD);
+/* Run-ahead depth in blocks for processors created from now on (1 = off; default 64 or FOLVE_AMD_RUN_AHEAD);
  * fh_processor_run_ahead: the depth a given processor was created with. */
 void fh_run_ahead_set(int blocks);
 int fh_run_ahead_get(void);

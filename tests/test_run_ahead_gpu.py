@@ -26,7 +26,7 @@ def depth():
     def set_depth(n):
         H.set_run_ahead(n)
     yield set_depth
-    H.set_run_ahead(32)
+    H.set_run_ahead(H.DEFAULT_RUN_AHEAD)
 
 
 def _call_log(sp, x, split=False):

@@ -57,13 +57,14 @@ int main(int argc, char** argv) {
     const char* conf = argv[1];
     const int nthreads = atoi(argv[2]), nblocks = atoi(argv[3]), batching = atoi(argv[4]);
     bool json = false;
-    int run_ahead = 1, file_blocks = 64, pin = 0;
+    int run_ahead = 1, file_blocks = 64, pin = 0, tune_knob = -1, tune_value = 0;   // tune=K:V: fe_engine_set_tuning on every engine (experiments)
     for (int i = 5; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "json") json = true;
         else if (a.rfind("run_ahead=", 0) == 0) run_ahead = atoi(a.c_str() + 10);
         else if (a.rfind("file_blocks=", 0) == 0) file_blocks = atoi(a.c_str() + 12);
         else if (a.rfind("pin=", 0) == 0) pin = atoi(a.c_str() + 4);
+        else if (a.rfind("tune=", 0) == 0) { tune_knob = atoi(a.c_str() + 5); tune_value = atoi(strchr(a.c_str(), ':') ? strchr(a.c_str(), ':') + 1 : "0"); }
     }
     fh_batching_set(batching, 0, 256);
     fh_run_ahead_set(run_ahead);
@@ -74,6 +75,8 @@ int main(int argc, char** argv) {
         if (!p) { fprintf(stderr, "processor %d: creation failed\n", i); return 1; }
         procs.push_back(p);
     }
+    if (tune_knob >= 0)
+        for (auto* p : procs) fe_engine_set_tuning(fh_processor_engine(p), tune_knob, tune_value);
     const int P = fh_processor_block_size(procs[0]);
     const int cin = fh_processor_input_channels(procs[0]), cout = fh_processor_output_channels(procs[0]);
     const int warm = std::max(8, 3 * run_ahead);                 // past the run-ahead ramp, clocks up
