@@ -79,6 +79,7 @@ ENGINE_SYMBOLS = [
     ("fe_batch_submit", _i, [_pvp, _i, _pvp, C.POINTER(_ll), _pvp, _pvp]),
     ("fe_ticket_wait", _i, [_vp]),
     ("fe_ticket_done", _i, [_vp]),
+    ("fe_batch_submit_peaks", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     ("fe_filter_use_count", _i, [_vp]),
     ("fe_device_local_cpulist", _i, [_i, C.c_char_p, C.c_size_t]),
     ("fe_batch_get_peaks", _i, [_pvp, _i, C.POINTER(_f), C.POINTER(_f)]),

@@ -95,6 +95,13 @@ struct fe_engine {
     float* dx_stage_out[2] = {};         // ... and output staging when the results leave by DMA too (FE_TUNE_DUPLEX_OUT = 2)
     size_t dx_stage_out_bytes[2] = {};
     hipEvent_t dx_k3[16] = {};           // "K3 of chunk c has finished"
+    // per-block maxima of submitted batches (fe_batch_submit_peaks): a few rotating device / page-locked pairs
+    struct PeakBuf {
+        unsigned int* dev = nullptr; unsigned int* host = nullptr; size_t cap = 0;    // blocks
+        bool in_use = false;             // a ticket has not handed its maxima out yet
+    };
+    PeakBuf pkb[4];
+    int pkb_next = 0;
     int duplex_out = 0;                  // 0 / 2: K3 -> device staging -> DMA out; 1: K3 stores into the callers' buffers
     hipEvent_t dx_free[2] = {};          // the batch that last used dx_stage[i] has finished
     bool dx_free_pending[2] = {};
@@ -132,6 +139,11 @@ struct fe_ticket {                  // a submitted batch whose outputs are not y
     hipEvent_t ev = nullptr;
     int lane = 0;                    // the lane its completion event is recorded on
     long long seq[2] = {0, 0};       // per lane: the sequence number of this batch there (0: lane not used)
+    // per-block maxima to hand out when the batch is done: (destination, first block in peaks_host, blocks)
+    const unsigned int* peaks_host = nullptr;
+    int peaks_slot = -1;
+    struct PeakDst { float* dst; size_t first; size_t blocks; };
+    std::vector<PeakDst> peaks_dst;
 };
 
 struct PathHost {
@@ -227,6 +239,7 @@ struct Item {
     const float* in;     // device
     float* out;          // device
     long long left;
+    unsigned int* blk_peaks = nullptr;   // device: this stream's per-block maxima of the call (advances with the rounds)
 };
 
 // One launch round over streams that share a filter.  Host-side stream state (ring position, block
@@ -241,7 +254,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     jobs.reserve(items.size());
     owners.reserve(items.size());
     int yunits = 0, max_blocks = 0;
-    bool in_pairs_ok = true, out_pairs_ok = true;
+    bool in_pairs_ok = true, out_pairs_ok = true, want_block_peaks = false;
     for (Item& it : items) {
         if (it.left <= 0) continue;
         fe_stream* s = it.s;
@@ -252,6 +265,8 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         j.out = it.out;
         j.fdl = s->fdl;
         j.peaks = s->peaks;
+        j.blk_peaks = it.blk_peaks;
+        if (it.blk_peaks) want_block_peaks = true;
         j.nframes = take;
         if (reinterpret_cast<uintptr_t>(it.in) & 15) in_pairs_ok = false;
         if (reinterpret_cast<uintptr_t>(it.out) & 15) out_pairs_ok = false;
@@ -308,6 +323,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     fk::Tuning tn = e->tuning;
     tn.host_io = e->host_io;
     tn.in_resident = e->in_resident;
+    if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
     tn.one_job = (nj == 1 && dj == e->jobs_host[slot]) ? e->jobs_host[slot] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
@@ -337,6 +353,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         s->blocks_done += j.nblocks;
         it.in += (size_t)j.nframes * f->ninp;
         it.out += (size_t)j.nframes * f->nout;
+        if (it.blk_peaks) it.blk_peaks += 2 * (size_t)j.nblocks;
         it.left -= j.nframes;
     }
     return FE_OK;
@@ -466,7 +483,8 @@ void plan_duplex(fe_stream* const* streams, int n, const long long* nframes, int
     p->first[++p->nc] = n;
 }
 int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int n, const float* const* host_in,
-               float* const* host_out, const long long* nframes, int lane, const DuplexPlan& p) {
+               float* const* host_out, const long long* nframes, int lane, const DuplexPlan& p,
+               unsigned int* pk_dev = nullptr, unsigned int* pk_host = nullptr, size_t pk_bytes = 0) {
     const bool dma_out = e->duplex_out != 1;
     if (!e->dx_ev[0]) {
         for (int i = 0; i < kDuplexChunks; ++i) HIP_TRY(hipEventCreateWithFlags(&e->dx_ev[i], hipEventDisableTiming));
@@ -522,6 +540,13 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
     } resident(e);
     const int nc = p.nc;
     const int* first = p.first;
+    if (pk_dev) {
+        // zeroed on the compute lanes, in front of every K3 (the copy streams stay pure DMA: a fill kernel between their
+        // copies cost a quarter of the pipeline's rate)
+        HIP_TRY(hipMemsetAsync(pk_dev, 0, pk_bytes, e->lanes[lane].st));
+        HIP_TRY(hipEventRecord(e->lanes[lane].xev, e->lanes[lane].st));
+        HIP_TRY(hipStreamWaitEvent(e->lanes[lane ^ 1].st, e->lanes[lane].xev, 0));
+    }
     for (int c = 0; c < nc; ++c) {
         const int l = (lane + c) & 1;
         for (int i = first[c]; i < first[c + 1]; ++i) {
@@ -557,6 +582,7 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
     const int other = lane ^ 1;
     HIP_TRY(hipEventRecord(e->lanes[other].xev, e->lanes[other].st));
     HIP_TRY(hipStreamWaitEvent(e->lanes[lane].st, e->lanes[other].xev, 0));
+    if (pk_dev) HIP_TRY(hipMemcpyAsync(pk_host, pk_dev, pk_bytes, hipMemcpyDeviceToHost, e->lanes[lane].st));   // behind every K3
     HIP_TRY(hipEventRecord(e->dx_free[par], e->lanes[lane].st));
     e->dx_free_pending[par] = true;
     return FE_OK;
@@ -579,7 +605,8 @@ static unsigned long long host_now_ns() {
 // peaks_out: optional [n][2] float bits fetched behind the outputs, under the same synchronisation.
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
                    const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr,
-                   hipEvent_t submit_event = nullptr, int lane = 0, long long* seq_out = nullptr) {
+                   hipEvent_t submit_event = nullptr, int lane = 0, long long* seq_out = nullptr,
+                   float* const* block_peaks = nullptr, fe_ticket* ticket = nullptr) {
     Lane& L = e->lanes[lane];
     const hipStream_t st = L.st;
     bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
@@ -697,6 +724,47 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             oo += (no + 3) & ~(size_t)3;
         }
     }
+    // per-block maxima (fe_batch_submit_peaks): one device array for the call, zeroed in front of the kernels, raised by K3,
+    // copied into page-locked memory behind them; the ticket hands the blocks out to their streams' arrays
+    unsigned int *pk_dev = nullptr, *pk_host = nullptr;
+    size_t pk_bytes = 0;
+    if (block_peaks && ticket && submit_event) {
+        size_t blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!block_peaks[i] || nframes[i] <= 0) continue;
+            const size_t nb = (size_t)((nframes[i] + streams[i]->f->P - 1) / streams[i]->f->P);
+            ticket->peaks_dst.push_back(fe_ticket::PeakDst{block_peaks[i], blocks, nb});
+            blocks += nb;
+        }
+        if (blocks) {
+            int slot = -1;
+            for (int k = 0; k < 4 && slot < 0; ++k) {
+                const int c = (e->pkb_next + k) % 4;
+                if (!e->pkb[c].in_use) slot = c;
+            }
+            if (slot < 0) return fail(FE_ERR_BUSY, "four batches with block maxima are outstanding: wait for their tickets");
+            e->pkb_next = (slot + 1) % 4;
+            fe_engine::PeakBuf& pb = e->pkb[slot];
+            if (pb.cap < blocks) {
+                if (pb.dev) HIP_TRY(hipFree(pb.dev));
+                if (pb.host) HIP_TRY(hipHostFree(pb.host));
+                pb.dev = nullptr; pb.host = nullptr; pb.cap = 0;
+                const size_t cap = std::max<size_t>(blocks * 2, 4096);
+                HIP_TRY(hipMalloc((void**)&pb.dev, cap * 2 * sizeof(unsigned int)));
+                HIP_TRY(hipHostMalloc((void**)&pb.host, cap * 2 * sizeof(unsigned int), hipHostMallocDefault));
+                pb.cap = cap;
+            }
+            pk_dev = pb.dev; pk_host = pb.host; pk_bytes = blocks * 2 * sizeof(unsigned int);
+            size_t k = 0;
+            for (int i = 0; i < n; ++i) {
+                if (!block_peaks[i] || nframes[i] <= 0) continue;
+                all[(size_t)i].blk_peaks = pk_dev + 2 * ticket->peaks_dst[k++].first;
+            }
+            pb.in_use = true;
+            ticket->peaks_host = pk_host;
+            ticket->peaks_slot = slot;
+        }
+    }
     // worth pipelining: several streams and enough bytes that the bus time dwarfs the extra events
     const bool pipelined = lane == 0 && !device_ptrs && !e->profiling && n >= 4 &&
                            (in_floats + out_floats) * sizeof(float) >= ((size_t)16 << 20);
@@ -710,8 +778,11 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
                 if (ni) HIP_TRY(hipMemcpyAsync(const_cast<float*>(all[(size_t)i].in), in[i], ni * sizeof(float), hipMemcpyHostToDevice, st));
             }
         }
-        int rc = duplex ? run_duplex(e, streams, all, n, host_in, host_out, nframes, lane, dplan) : run_groups(e, streams, all, 0, n, lane);
+        if (pk_dev && !duplex) HIP_TRY(hipMemsetAsync(pk_dev, 0, pk_bytes, st));
+        int rc = duplex ? run_duplex(e, streams, all, n, host_in, host_out, nframes, lane, dplan, pk_dev, pk_host, pk_bytes)
+                        : run_groups(e, streams, all, 0, n, lane);
         if (rc) return rc;
+        if (pk_dev && !duplex) HIP_TRY(hipMemcpyAsync(pk_host, pk_dev, pk_bytes, hipMemcpyDeviceToHost, st));
         if (!device_ptrs) {
             for (int i = 0; i < n; ++i) {
                 const size_t no = (size_t)nframes[i] * streams[i]->f->nout;
@@ -862,6 +933,10 @@ static void engine_release(fe_engine* e) {
     }
     for (hipEvent_t ev : e->dx_ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->dx_k3) if (ev) (void)hipEventDestroy(ev);
+    for (fe_engine::PeakBuf& pb : e->pkb) {
+        if (pb.dev) (void)hipFree(pb.dev);
+        if (pb.host) (void)hipHostFree(pb.host);
+    }
     for (int i = 0; i < 2; ++i) {
         if (e->dx_free[i]) (void)hipEventDestroy(e->dx_free[i]);
         if (e->dx_stage[i]) (void)hipFree(e->dx_stage[i]);
@@ -1298,6 +1373,11 @@ int fe_batch_process(fe_stream* const* streams, int n, const float* const* in, c
 
 int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, const long long* nframes,
                     float* const* out, fe_ticket** ticket) {
+    return fe_batch_submit_peaks(streams, n, in, nframes, out, nullptr, ticket);
+}
+
+int fe_batch_submit_peaks(fe_stream* const* streams, int n, const float* const* in, const long long* nframes,
+                          float* const* out, float* const* block_peaks, fe_ticket** ticket) {
     if (!ticket) return fail(FE_ERR_PARAM, "null ticket");
     *ticket = nullptr;
     if (n < 1 || !streams || !in || !nframes || !out) return fail(FE_ERR_PARAM, "bad batch arguments");
@@ -1320,8 +1400,9 @@ int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, co
         delete t;
         return fail(FE_ERR_DEVICE, "hipEventCreate failed");
     }
-    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev, lane, t->seq);
+    const int rc = process_locked(e, streams, n, in, nframes, out, FE_HOST_PTRS, nullptr, t->ev, lane, t->seq, block_peaks, t);
     if (rc) {
+        if (t->peaks_slot >= 0) e->pkb[t->peaks_slot].in_use = false;
         e->ticket_events.push_back(t->ev);      // (never recorded: nothing pends on it)
         delete t;
         return rc;
@@ -1371,10 +1452,13 @@ int fe_ticket_wait(fe_ticket* t) {
         if (done) {
             for (int l = 0; l < kLanes; ++l)
                 if (t->seq[l] > e->lanes[l].done) e->lanes[l].done = t->seq[l];
+            if (rc == FE_OK)
+                for (const fe_ticket::PeakDst& d : t->peaks_dst) memcpy(d.dst, t->peaks_host + 2 * d.first, d.blocks * 2 * sizeof(float));
             e->ticket_events.push_back(t->ev);
         } else {
             (void)hipEventDestroy(t->ev);        // may still be pending: never recycled
         }
+        if (t->peaks_slot >= 0) e->pkb[t->peaks_slot].in_use = false;
     }
     delete t;
     engine_release(e);

@@ -13,6 +13,8 @@ struct BatchScheduler::Request {
     const float* in = nullptr;
     long long frames = 0;
     float* out = nullptr;
+    float* peaks = nullptr;                 // per-block maxima wanted here
+    bool peaks_filled = false;
     long long blocks = 0;
     int rc = 0;
     std::string error;
@@ -63,12 +65,13 @@ void BatchScheduler::ReleaseEngine(fe_engine* engine) {
     Schedulers().erase(engine);
 }
 
-BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, long long frames, float* out) {
+BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, long long frames, float* out, float* block_peaks) {
     Request* r = new Request();
     r->s = s;
     r->in = in;
     r->frames = frames;
     r->out = out;
+    r->peaks = block_peaks;
     const int P = fe_stream_block_size(s);
     r->blocks = P > 0 ? (frames + P - 1) / P : 0;
     std::unique_lock<std::mutex> lk(mu_);
@@ -101,7 +104,7 @@ bool BatchScheduler::Ready(Request* r) {
     return false;
 }
 
-int BatchScheduler::Wait(Request* r, std::string* error) {
+int BatchScheduler::Wait(Request* r, std::string* error, bool* peaks_filled) {
     std::unique_lock<std::mutex> lk(mu_);
     while (r->state != kDone) {
         if (r->state == kFlying) {
@@ -127,6 +130,7 @@ int BatchScheduler::Wait(Request* r, std::string* error) {
     }
     const int rc = r->rc;
     if (error) *error = r->error;
+    if (peaks_filled) *peaks_filled = r->peaks_filled;
     lk.unlock();
     delete r;
     return rc;
@@ -170,6 +174,7 @@ void BatchScheduler::CompleteLocked(std::unique_lock<std::mutex>& lk, const std:
     for (Request* q : settled) {
         q->rc = rc;
         if (rc != 0) q->error = msg;
+        q->peaks_filled = rc == 0 && q->peaks != nullptr;
     }
     b->done = true;
     flying_.erase(std::remove(flying_.begin(), flying_.end(), b), flying_.end());
@@ -217,18 +222,22 @@ void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
         // ---- outside the lock: the engine call (a few tens of microseconds of launches) ----
         std::vector<fe_stream*> ss(n);
         std::vector<const float*> ins(n);
-        std::vector<float*> outs(n);
+        std::vector<float*> outs(n), pks(n);
         std::vector<long long> nfr(n), before(n);
+        bool any_peaks = false;
         for (size_t i = 0; i < n; ++i) {
             const Request* r = b->reqs[i];
             ss[i] = r->s;
             ins[i] = r->in;
             outs[i] = r->out;
+            pks[i] = r->peaks;
+            any_peaks = any_peaks || r->peaks != nullptr;
             nfr[i] = r->frames;
             before[i] = fe_stream_blocks_done(r->s);
         }
         fe_ticket* ticket = nullptr;
-        const int rc = fe_batch_submit(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(), &ticket);
+        const int rc = fe_batch_submit_peaks(ss.data(), static_cast<int>(n), ins.data(), nfr.data(), outs.data(),
+                                             any_peaks ? pks.data() : nullptr, &ticket);
         if (rc != 0) {
             // Not submitted (a buffer outside its stream's bound memory, or a launch round refused).  A round that
             // fails leaves its streams where they were: those requests run one by one, each with its own status, so

@@ -63,9 +63,12 @@ public:
     // Enqueue `frames` interleaved frames (ceil(frames / block) blocks, the last zero-padded) of stream `s`:
     // never waits for the GPU.  `in` and `out` must lie in page-locked memory bound to the stream and stay
     // untouched until Wait returns.  One request per stream at a time.
-    Request* Submit(fe_stream* s, const float* in, long long frames, float* out);
+    // block_peaks (optional): room for 2 floats per block — when the request comes back through a ticket the engine has
+    // filled in every block's signed maximum (never below 0) and maximum magnitude (fe_batch_submit_peaks).
+    Request* Submit(fe_stream* s, const float* in, long long frames, float* out, float* block_peaks = nullptr);
     // Blocks until the request has been computed; returns the engine's status for THIS request and frees it.
-    int Wait(Request* r, std::string* error);
+    // *peaks_filled: block_peaks holds the maxima (false after the block-by-block fallback of a refused batch: scan the output).
+    int Wait(Request* r, std::string* error, bool* peaks_filled = nullptr);
     // True once Wait would not block.
     bool Ready(Request* r);
 

@@ -123,6 +123,7 @@ void fh_processor_write_processed_to(fh_processor* p, fh_write_fn write, void* u
     SP(p)->WriteProcessed(&s, sample_count);
 }
 void fh_run_ahead_set(int blocks) { SoundProcessor::SetRunAhead(blocks); }
+void fh_device_peaks_set(int on) { SoundProcessor::SetDevicePeaks(on != 0); }
 int fh_run_ahead_get(void) { return SoundProcessor::RunAhead(); }
 int fh_processor_run_ahead(const fh_processor* p) { return SP(p)->run_ahead(); }
 int fh_processor_is_input_buffer_complete(const fh_processor* p) { return SP(p)->is_input_buffer_complete(); }

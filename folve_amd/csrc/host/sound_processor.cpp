@@ -32,11 +32,14 @@ static time_t GetModificationTime(const std::string& filename) {
 
 namespace {
 std::atomic<int> g_run_ahead{-1};          // -1: not decided yet (environment)
+std::atomic<bool> g_device_peaks{true};
 const int kMaxRunAhead = 1024;
 // 64 blocks = 12 s of 44.1 kHz audio per chunk: 8 MB of page-locked ring and 12.6 MB of delay line per open stereo file
 // at 256 k taps.  Measured with 64 file threads on one MI355X: depth 8: 5.5, 32: 8.0, 64: 9.0, 128: 9.2 Gsamples/s.
 const int kDefaultRunAhead = 64;
 }  // namespace
+
+void SoundProcessor::SetDevicePeaks(bool on) { g_device_peaks.store(on); }
 
 void SoundProcessor::SetRunAhead(int blocks) { g_run_ahead.store(std::max(1, std::min(blocks, kMaxRunAhead))); }
 
@@ -142,6 +145,7 @@ SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg,
             p += ChunkFloats(config, run_depth_);
         }
         tail_ = new float[static_cast<size_t>(config.fragm) * config.ninp];
+        for (Chunk& c : chunks_) c.peaks = new float[2 * static_cast<size_t>(run_depth_)];
     }
     Reset();
 }
@@ -153,6 +157,7 @@ SoundProcessor::~SoundProcessor() {
     if (buffer_pinned_) fe_host_free(buffer_);
     else delete[] buffer_;
     delete[] tail_;
+    for (Chunk& c : chunks_) delete[] c.peaks;
 }
 
 int SoundProcessor::device() const { return fe_engine_device(zita_config_.engine); }
@@ -180,8 +185,10 @@ bool SoundProcessor::ReadChunk(FrameSource* in, Chunk* c) {
 // collected by SettleChunk; with the combiner off the engine is called synchronously here.
 void SoundProcessor::SubmitChunk(Chunk* c) {
     const long long frames = static_cast<long long>(c->blocks) * zita_config_.fragm;
+    c->peaks_valid = false;
     if (BatchScheduler::Enabled()) {
-        c->request = BatchScheduler::ForEngine(zita_config_.engine)->Submit(stream_, c->in, frames, c->out);
+        c->request = BatchScheduler::ForEngine(zita_config_.engine)->Submit(stream_, c->in, frames, c->out,
+                                                                             g_device_peaks.load() ? c->peaks : NULL);
         return;
     }
     c->request = NULL;
@@ -196,7 +203,8 @@ void SoundProcessor::SubmitChunk(Chunk* c) {
 void SoundProcessor::SettleChunk(Chunk* c) {
     if (!c->request) return;
     std::string error;
-    const int rc = BatchScheduler::ForEngine(zita_config_.engine)->Wait(static_cast<BatchScheduler::Request*>(c->request), &error);
+    const int rc = BatchScheduler::ForEngine(zita_config_.engine)->Wait(static_cast<BatchScheduler::Request*>(c->request), &error,
+                                                                       &c->peaks_valid);
     c->request = NULL;
     if (rc != 0) {
         Logf("GPU convolution failed (%d): %s", rc, error.c_str());
@@ -299,8 +307,14 @@ void SoundProcessor::ScanPeaks(const float* v, size_t n) {
 // and the maximum is taken here over the returned frames, signed as cc:120-123 does.
 void SoundProcessor::Process() {
     if (ring_block_) {
-        // a block of the run-ahead ring: computed already (its chunk was settled when it became current)
-        if (ok_) ScanPeaks(ring_block_, static_cast<size_t>(input_pos_) * output_channels());
+        // a block of the run-ahead ring: computed already (its chunk was settled when it became current), its maxima too
+        if (cur_ && cur_->peaks_valid) {
+            const float* pk = cur_->peaks + 2 * static_cast<size_t>(cur_->next - 1);
+            if (pk[0] > max_out_value_observed_) max_out_value_observed_ = pk[0];
+            if (pk[1] > max_abs_value_observed_) max_abs_value_observed_ = pk[1];
+        } else if (ok_) {
+            ScanPeaks(ring_block_, static_cast<size_t>(input_pos_) * output_channels());
+        }
         output_pos_ = 0;
         return;
     }

@@ -21,7 +21,9 @@
 // file costs one block's latency.  Only WHOLE blocks run ahead: the short last block of a file stays in the
 // block buffer unprocessed, as in the reference, so that the gapless hand-over (PassoverProcessor,
 // convolve-file-handler.cc:328-351) can top it up from the next file — at that point the ring is empty by
-// construction.  max_output_value() advances block by block as blocks are handed out, not as they are computed.
+// construction.  max_output_value() advances block by block as blocks are handed out, not as they are computed: K3 reduces
+// every block's maxima on the GPU (fe_batch_submit_peaks) and the processor folds a block's two numbers in when the block
+// is handed out — the reference's scan over the returned frames (sound-processor.cc:116-125) happens once, on the device.
 #pragma once
 
 #include <time.h>
@@ -63,6 +65,9 @@ public:
     // pattern).  Applies to processors created afterwards.  Default 64, or FOLVE_AMD_RUN_AHEAD.
     static void SetRunAhead(int blocks);
     static int RunAhead();
+    // Where a run-ahead block's maxima come from: the GPU (K3 reduces every block; default) or a scan of the block on
+    // the caller's thread when it is handed out (what the reference does, sound-processor.cc:116-125).
+    static void SetDevicePeaks(bool on);
 private:
     static SoundProcessor* CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
 public:
@@ -117,6 +122,8 @@ private:
         int blocks = 0;                 // whole blocks it holds
         int next = 0;                   // next block to hand out
         void* request = nullptr;        // BatchScheduler::Request while on the GPU
+        float* peaks = nullptr;         // [blocks][2]: every block's signed maximum and maximum magnitude, from the GPU
+        bool peaks_valid = false;       // ... filled in (else the block is scanned when it is handed out)
     };
     SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth);
     void Process();

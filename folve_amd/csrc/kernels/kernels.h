@@ -19,6 +19,7 @@ struct StreamJob {
     float* out;             // interleaved [nframes][cout]  (device)
     float2* fdl;            // [cin][ring][P]
     unsigned int* peaks;    // [2] float bits: max(0, signed max), max |.|
+    unsigned int* blk_peaks;// NULL, or [nblocks][2]: the same two maxima per block of this call (zeroed by the host; K3 raises them)
     long long nframes;      // frames valid in this call (last block may be short)
     int nblocks;            // ceil(nframes / P)
     int slot0;              // ring slot of this call's first block

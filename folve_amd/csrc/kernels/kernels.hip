@@ -756,6 +756,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
         // non-negative floats order like their bit patterns
         peak_raise(job.peaks + 0, pk_s);
         peak_raise(job.peaks + 1, pk_a);
+        if (job.blk_peaks) {                                   // per-block maxima: this workgroup holds one block (the launcher sees to it)
+            atomicMax(job.blk_peaks + 2 * b + 0, __float_as_uint(pk_s));
+            atomicMax(job.blk_peaks + 2 * b + 1, __float_as_uint(pk_a));
+        }
     }
 }
 
@@ -880,6 +884,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(con
     if ((tid & 63) == 0) {
         peak_raise(job.peaks + 0, pk_s);
         peak_raise(job.peaks + 1, pk_a);
+        if (job.blk_peaks) {                                   // per-block maxima: this workgroup holds one block (the launcher sees to it)
+            atomicMax(job.blk_peaks + 2 * b + 0, __float_as_uint(pk_s));
+            atomicMax(job.blk_peaks + 2 * b + 1, __float_as_uint(pk_a));
+        }
     }
 }
 
@@ -1084,6 +1092,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     if ((tid & 63) == 0) {
         peak_raise(job.peaks + 0, pk_s);
         peak_raise(job.peaks + 1, pk_a);
+        if (job.blk_peaks) {                                   // per-block maxima: this workgroup holds one block (the launcher sees to it)
+            atomicMax(job.blk_peaks + 2 * b0 + 0, __float_as_uint(pk_s));
+            atomicMax(job.blk_peaks + 2 * b0 + 1, __float_as_uint(pk_a));
+        }
     }
 }
 
@@ -1198,6 +1210,10 @@ __global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void inverse_pair_kernel(c
     if ((t & 63) == 0) {
         peak_raise(job.peaks + 0, pk_s);
         peak_raise(job.peaks + 1, pk_a);
+        if (job.blk_peaks) {                                   // per-block maxima: this workgroup holds one block (the launcher sees to it)
+            atomicMax(job.blk_peaks + 2 * b + 0, __float_as_uint(pk_s));
+            atomicMax(job.blk_peaks + 2 * b + 1, __float_as_uint(pk_a));
+        }
     }
 }
 

@@ -42,6 +42,7 @@ HOST_SYMBOLS = [
     ("fh_batching_stats", None, [C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
     ("fh_batching_stats2", None, [C.POINTER(_ll)] * 5),
     ("fh_run_ahead_set", None, [_i]),
+    ("fh_device_peaks_set", None, [_i]),
     ("fh_run_ahead_get", _i, []),
     ("fh_processor_run_ahead", _i, [_vp]),
     ("fh_processor_fill_buffer_from", _i, [_vp, _vp, _vp]),

@@ -158,6 +158,12 @@ int fe_batch_process(fe_stream *const *streams, int n, const float *const *in, c
 typedef struct fe_ticket fe_ticket;
 int fe_batch_submit(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
                     float *const *out, fe_ticket **ticket);
+/* fe_batch_submit that also returns per-BLOCK maxima: block_peaks[i] (NULL: not wanted for stream i) receives, when the
+ * ticket has been waited for, two floats for each of stream i's ceil(nframes[i] / P) blocks of this call — the maximum of
+ * the block's output samples compared as sound-processor.cc:120-123 compares them (signed, never below 0) and the maximum
+ * magnitude.  What folve::SoundProcessor feeds max_output_value() with, block by block, instead of rescanning its output. */
+int fe_batch_submit_peaks(fe_stream *const *streams, int n, const float *const *in, const long long *nframes,
+                          float *const *out, float *const *block_peaks, fe_ticket **ticket);
 int fe_ticket_wait(fe_ticket *ticket);
 /* 1 if fe_ticket_wait would return without waiting, 0 if the batch is still on the GPU, negative on a device
  * error; does not consume the ticket. */

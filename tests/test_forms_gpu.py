@@ -459,3 +459,51 @@ def test_channel_pair_kernels_match_the_per_channel_ones(tuned, oracle, channels
     assert _rms(outs[0][0][1] - sp.run(xs[1])) <= TOL
     y64 = oracle.linear_convolution_f64(xs[0], dense_taps(paths, size), channels)
     assert _rms(outs[0][0][0] - y64) <= TOL
+
+
+def test_block_peaks_of_a_submitted_batch(tuned, oracle):
+    """fe_batch_submit_peaks: every block's signed maximum (never below 0) and maximum magnitude, reduced by K3 on the
+    GPU, for small batches (pair / general kernels) and for one big enough for the duplex pipeline (walkers, DMA both
+    ways); streams that do not ask get nothing; a stream's running peaks are unchanged by it."""
+    import ctypes
+    L = fa.lib()
+    size, C = 60000, 2
+    rng = np.random.default_rng(123)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+    _, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+    P = flt.block_size
+    for S, nblk in ((3, 2), (5, 24), (40, 16)):
+        bufs, arrs, pk = [], [], []
+        streams = [flt.open_stream(nblk) for _ in range(S)]
+        for s_ in streams:
+            b = ctypes.c_void_p()
+            assert L.fe_host_alloc(nblk * P * C * 4, ctypes.byref(b)) == 0
+            assert L.fe_stream_bind_host_buffer(s_.h, b, nblk * P * C * 4) == 0
+            bufs.append(b)
+            a = np.ctypeslib.as_array(ctypes.cast(b, ctypes.POINTER(ctypes.c_float)), shape=(nblk * P, C))
+            a[:] = rng.uniform(-1, 1, (nblk * P, C)).astype(np.float32) * rng.uniform(0.2, 1.0)
+            arrs.append(a)
+            pk.append(np.full((nblk, 2), -7.0, np.float32))
+        xs = [a.copy() for a in arrs]
+        ss = (ctypes.c_void_p * S)(*[s_.h for s_ in streams])
+        pp = (ctypes.c_void_p * S)(*[b.value for b in bufs])
+        nn = (ctypes.c_longlong * S)(*([nblk * P] * S))
+        kk = (ctypes.c_void_p * S)(*[pk[i].ctypes.data if i != 1 else None for i in range(S)])   # stream 1 does not ask
+        t = ctypes.c_void_p()
+        assert L.fe_batch_submit_peaks(ss, S, pp, nn, pp, kk, ctypes.byref(t)) == 0
+        assert L.fe_ticket_wait(t) == 0
+        for i in range(S):
+            y = arrs[i].reshape(nblk, P * C)
+            if i == 1:
+                assert np.all(pk[i] == -7.0)
+                continue
+            assert np.array_equal(pk[i][:, 0], np.maximum(0.0, y.max(axis=1))), (S, i)
+            assert np.array_equal(pk[i][:, 1], np.abs(y).max(axis=1)), (S, i)
+            run = streams[i].peaks()
+            assert run[0] == max(0.0, float(y.max())) and run[1] == float(np.abs(y).max())
+        y64 = oracle.linear_convolution_f64(xs[0], dense_taps(paths, size), C)
+        assert _rms(arrs[0] - y64) <= TOL
+        for s_ in streams:
+            s_.close()
+        for b in bufs:
+            L.fe_host_free(b)

@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
         else if (a.rfind("run_ahead=", 0) == 0) run_ahead = atoi(a.c_str() + 10);
         else if (a.rfind("file_blocks=", 0) == 0) file_blocks = atoi(a.c_str() + 12);
         else if (a.rfind("pin=", 0) == 0) pin = atoi(a.c_str() + 4);
+        else if (a.rfind("peaks=", 0) == 0) fh_device_peaks_set(atoi(a.c_str() + 6));
         else if (a.rfind("tune=", 0) == 0) { tune_knob = atoi(a.c_str() + 5); tune_value = atoi(strchr(a.c_str(), ':') ? strchr(a.c_str(), ':') + 1 : "0"); }
     }
     fh_batching_set(batching, 0, 256);
