@@ -1,3 +1,6 @@
+// This file restates the interface and behaviour of folve's processor-pool.cc, Copyright (C) 2012 Henner Zeller
+// <h.zeller@acm.org>, free software under the GNU General Public License, version 3 or (at your option) any later
+// version; this restatement is distributed under the same terms, WITHOUT ANY WARRANTY (<http://www.gnu.org/licenses/>).
 #include "processor_pool.h"
 
 #include <stdarg.h>

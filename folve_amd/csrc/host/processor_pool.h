@@ -1,3 +1,6 @@
+// This file restates the interface and behaviour of folve's processor-pool.h, Copyright (C) 2012 Henner Zeller
+// <h.zeller@acm.org>, free software under the GNU General Public License, version 3 or (at your option) any later
+// version; this restatement is distributed under the same terms, WITHOUT ANY WARRANTY (<http://www.gnu.org/licenses/>).
 // processor_pool.h — drop-in for folve's ProcessorPool (processor-pool.h:30-55).
 //
 // Same contract: an object pool of SoundProcessors keyed by the resolved

@@ -1,3 +1,6 @@
+// This file restates the interface and behaviour of folve's sound-processor.h, Copyright (C) 2012 Henner Zeller
+// <h.zeller@acm.org>, free software under the GNU General Public License, version 3 or (at your option) any later
+// version; this restatement is distributed under the same terms, WITHOUT ANY WARRANTY (<http://www.gnu.org/licenses/>).
 // sound_processor.h — drop-in for folve's SoundProcessor on top of the GPU engine.
 //
 // Public surface and behaviour follow /root/reference/sound-processor.h:28-85 and

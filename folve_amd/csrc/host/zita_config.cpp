@@ -1,3 +1,10 @@
+// zita_config.cpp — the jconvolver configuration loader folve uses, on top of the GPU engine's filter ABI.
+//
+// This file restates the grammar, the error paths and the log messages of folve's zita-config.cc / zita-fconfig.cc,
+// which derive from config.cc of jconvolver 0.9.2: Copyright (C) 2006-2011 Fons Adriaensen <fons@linuxaudio.org>,
+// modifications for folve Copyright (C) 2012 Henner Zeller <h.zeller@acm.org>; free software under the GNU General
+// Public License, version 2 or (at your option) any later version.  This restatement is distributed under the same
+// terms, WITHOUT ANY WARRANTY.  The impulse-file reader (impulse_file.cpp) and everything below fe_filter_* are original.
 #include "zita_config.h"
 
 #include <ctype.h>

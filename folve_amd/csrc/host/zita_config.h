@@ -1,3 +1,6 @@
+// This file restates the interface and behaviour of folve's zita-config.h (itself derived from jconvolver's config.h, Copyright (C) 2006-2011 Fons Adriaensen, GPL v2 or later) and, Copyright (C) 2012 Henner Zeller
+// <h.zeller@acm.org>, free software under the GNU General Public License, version 3 or (at your option) any later
+// version; this restatement is distributed under the same terms, WITHOUT ANY WARRANTY (<http://www.gnu.org/licenses/>).
 // zita_config.h — jconvolver-format filter configuration loader.
 //
 // Behavioural mirror of the reference loader with `Convproc*` replaced by the
