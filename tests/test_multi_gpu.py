@@ -66,3 +66,20 @@ def test_harness_over_two_router_slots_with_numa_placement(tmp_path):
     assert out["ok"] and out["threads"] == 8 and out["run_ahead"] == 8 and out["numa_pin"]
     assert out["gpus"]["0"]["streams"] == 8                                    # (two slots, one physical device)
     assert out["blocks_per_s"] > 0 and out["requests"] < 8 * 256              # blocks travelled in chunks
+
+
+def test_harness_verifies_the_duplex_pipeline_under_contention(tmp_path):
+    """48 native file threads with run-ahead 32 — big combined batches, the engine's duplex DMA pipeline, per-block maxima
+    from the GPU — and afterwards every thread's output and peak compared (verify=1) with the same file pulled one block per
+    engine call by a single thread without the combiner."""
+    exe = os.path.join(ROOT, "tools", "dropin", "dropin_threads")
+    if not os.path.exists(exe):
+        pytest.skip("tools/dropin/dropin_threads not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dropin"))
+    import make_conf
+    conf = make_conf.write(str(tmp_path), 100000)
+    r = subprocess.run([exe, conf, "48", "160", "1", "json", "run_ahead=32", "verify=1", "file_blocks=160"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["verified_rms"] is not None and out["verified_rms"] <= 2e-6
+    assert out["largest_batch_blocks"] >= 512                                  # (>= 32 MB each way: the duplex path ran)

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@ namespace {
 struct File {                      // what a thread reads from and writes to
     std::vector<float> data;       // cyclic source, `cycle` frames
     std::vector<float> sink;       // one block
+    std::vector<float>* keep = nullptr;   // verify=1: everything written, in order
     long long left = 0;            // frames until end of file
     size_t pos = 0;                // frame position inside the cycle
     size_t cycle = 0;
@@ -48,6 +50,7 @@ int read_cb(void* user, float* dst, int frames) {
 int write_cb(void* user, const float* src, int frames) {
     File* f = static_cast<File*>(user);
     memcpy(f->sink.data(), src, sizeof(float) * (size_t)frames * f->cout);
+    if (f->keep) f->keep->insert(f->keep->end(), src, src + (size_t)frames * f->cout);
     return frames;
 }
 }  // namespace
@@ -57,6 +60,7 @@ int main(int argc, char** argv) {
     const char* conf = argv[1];
     const int nthreads = atoi(argv[2]), nblocks = atoi(argv[3]), batching = atoi(argv[4]);
     bool json = false;
+    int verify = 0;                // 1: keep every thread's output and compare it with the same file pulled one block per call by one thread
     int run_ahead = 1, file_blocks = 64, pin = 0, tune_knob = -1, tune_value = 0;   // tune=K:V: fe_engine_set_tuning on every engine (experiments)
     for (int i = 5; i < argc; ++i) {
         const std::string a = argv[i];
@@ -65,6 +69,7 @@ int main(int argc, char** argv) {
         else if (a.rfind("file_blocks=", 0) == 0) file_blocks = atoi(a.c_str() + 12);
         else if (a.rfind("pin=", 0) == 0) pin = atoi(a.c_str() + 4);
         else if (a.rfind("peaks=", 0) == 0) fh_device_peaks_set(atoi(a.c_str() + 6));
+        else if (a.rfind("verify=", 0) == 0) verify = atoi(a.c_str() + 7);
         else if (a.rfind("tune=", 0) == 0) { tune_knob = atoi(a.c_str() + 5); tune_value = atoi(strchr(a.c_str(), ':') ? strchr(a.c_str(), ':') + 1 : "0"); }
     }
     fh_batching_set(batching, 0, 256);
@@ -84,6 +89,8 @@ int main(int argc, char** argv) {
     std::atomic<int> ready{0};
     std::atomic<bool> go{false};
     std::vector<std::vector<float>> lat((size_t)nthreads);
+    std::vector<std::vector<float>> kept((size_t)nthreads);
+    std::vector<float> peak_seen((size_t)nthreads, 0.f);
     std::vector<std::thread> th;
     long long r0, k0, b0, l0, o0;
     for (int t = 0; t < nthreads; ++t) {
@@ -111,10 +118,16 @@ int main(int argc, char** argv) {
                 }
             };
             pull(warm, nullptr);
+            if (verify) {                                         // the timed file starts from silence, from the start of the cycle
+                fh_processor_reset(p);
+                f.pos = 0;
+                f.keep = &kept[(size_t)t];
+            }
             lat[(size_t)t].reserve((size_t)nblocks);
             ready.fetch_add(1);
             while (!go.load()) std::this_thread::yield();
             pull(nblocks, &lat[(size_t)t]);
+            peak_seen[(size_t)t] = fh_processor_max_output_value(p);
         });
     }
     while (ready.load() < nthreads) std::this_thread::yield();
@@ -130,6 +143,42 @@ int main(int argc, char** argv) {
     std::sort(all.begin(), all.end());
     const double blocks = (double)nthreads * nblocks;
     int ok = 1;
+    double worst_rms = 0.0;
+    if (verify) {
+        // the same files once more, one after the other, one block per engine call, no combiner: what the reference's call
+        // pattern computes on this engine; the run above must agree within float32 rounding (other kernel forms), peaks too
+        fh_run_ahead_set(1);
+        fh_batching_set(0, 0, -1);
+        fh_processor* q = fh_processor_create(conf, 44100, 2);
+        for (int t = 0; t < nthreads && q; ++t) {
+            std::mt19937 rng(100 + t);
+            std::uniform_real_distribution<float> u(-1.f, 1.f);
+            File f;
+            f.cin = cin; f.cout = cout;
+            f.cycle = (size_t)std::max(1, std::min(file_blocks, nblocks)) * P;
+            f.data.resize(f.cycle * cin);
+            f.sink.resize((size_t)P * cout);
+            for (auto& v : f.data) v = u(rng);
+            std::vector<float> ref;
+            f.keep = &ref;
+            f.left = (long long)nblocks * P;
+            fh_processor_reset(q);
+            for (long long todo = f.left; todo > 0;) {
+                const int r = fh_processor_fill_buffer_from(q, read_cb, &f);
+                if (r <= 0) break;
+                fh_processor_write_processed_to(q, write_cb, &f, r);
+                todo -= r;
+            }
+            const std::vector<float>& got = kept[(size_t)t];
+            double e = 0.0;
+            if (got.size() != ref.size()) { e = 1e9; }
+            else { for (size_t i = 0; i < ref.size(); ++i) { const double dlt = (double)got[i] - ref[i]; e += dlt * dlt; } e = std::sqrt(e / (double)std::max<size_t>(1, ref.size())); }
+            if (std::fabs(peak_seen[(size_t)t] - fh_processor_max_output_value(q)) > 1e-5) e = std::max(e, 1.0);
+            worst_rms = std::max(worst_rms, e);
+        }
+        if (q) fh_processor_destroy(q);
+        if (!(worst_rms <= 2e-6)) ok = 0;
+    }
     std::map<int, int> per_gpu;
     for (auto* p : procs) { ok &= fh_processor_ok(p); per_gpu[fh_processor_device(p)]++; }
     std::string gpus = "{";
@@ -140,12 +189,14 @@ int main(int argc, char** argv) {
         gpus += b;
     }
     gpus += "}";
+    char rms_txt[32];
+    snprintf(rms_txt, sizeof(rms_txt), "%.3g", worst_rms);
     if (json) {
         printf("{\"threads\": %d, \"combiner\": %s, \"run_ahead\": %d, \"blocks_per_s\": %.0f, \"msamples_per_s\": %.1f, \"block_latency_us_median\": %.1f, "
                "\"block_latency_us_p99\": %.1f, \"requests\": %lld, \"engine_calls\": %lld, \"largest_batch_blocks\": %lld, \"overlapped_batches\": %lld, "
-               "\"gpus\": %s, \"numa_pin\": %s, \"ok\": %s}\n",
+               "\"gpus\": %s, \"numa_pin\": %s, \"verified_rms\": %s, \"ok\": %s}\n",
                nthreads, batching ? "true" : "false", run_ahead, blocks / dt, blocks * P * cout / dt / 1e6, all[all.size() / 2], all[all.size() * 99 / 100],
-               r1 - r0, b1 - b0, l1, o1 - o0, gpus.c_str(), pin ? "true" : "false", ok ? "true" : "false");
+               r1 - r0, b1 - b0, l1, o1 - o0, gpus.c_str(), pin ? "true" : "false", verify ? rms_txt : "null", ok ? "true" : "false");
         for (auto* p : procs) fh_processor_destroy(p);
         return ok ? 0 : 1;
     }

@@ -10,10 +10,10 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad, t0 = 0, time.time()
 for c in range(cases):
-    size = int(rng.choice([9000, 20000, 60000, 65536, 100000, 131072, 200000, 262144, 270000]))
-    ch = int(rng.integers(1, 3))
+    size = int(rng.choice([9000, 20000, 60000, 65536, 100000, 131072, 200000, 262144, 270000, 524288, 600000, 1048576]))
+    ch = int(rng.choice([1, 2, 2, 4, 6, 8]))                 # (4, 6, 8: the channel-pair K1 / K3)
     S = int(rng.integers(1, 7))
-    T = int(rng.integers(1, 90))
+    T = int(rng.integers(1, 90)) if size <= 270000 else int(rng.integers(1, 200))
     flt = fa.Filter(eng, ch, ch, size)
     for k in range(ch):
         n = int(rng.integers(1, size + 1))
@@ -26,12 +26,14 @@ for c in range(cases):
     maxb = max(-(-x.shape[0] // P) for call in calls for x in call)
     outs = {}
     runlen = int(rng.choice([1, 2, 3, 4, 8, 16, 32]))
-    for name, knobs in (("general", dict(mac_form=1, fft_form=1)), ("walk", dict(mac_form=100, fft_form=2, fwd_run=runlen, inv_run=runlen)),
+    lpb, tiles = int(rng.choice([0, 1, 2, 4])), int(rng.choice([0, 1, 2, 3, 7]))       # the walk's lanes per bin and time tiles
+    base = dict(walk_lpb=0, walk_tiles=0)
+    for name, knobs in (("general", dict(mac_form=1, fft_form=1)), ("walk", dict(mac_form=100, fft_form=2, fwd_run=runlen, inv_run=runlen, walk_lpb=lpb, walk_tiles=tiles)),
                         ("slide16", dict(mac_form=16, fft_form=2, fwd_run=0, inv_run=0)), ("auto", dict(mac_form=0, fft_form=0, fwd_run=0, inv_run=0))):
-        eng.set_tuning(**knobs)
+        eng.set_tuning(**dict(base, **knobs))
         st = [flt.open_stream(maxb) for _ in range(S)]
         outs[name] = [fa.batch_process(st, call) for call in calls]
-    eng.set_tuning(mac_form=0, fft_form=0, fwd_run=0, inv_run=0)
+    eng.set_tuning(mac_form=0, fft_form=0, fwd_run=0, inv_run=0, walk_lpb=0, walk_tiles=0)
     worst = 0.0
     for name in ("walk", "slide16", "auto"):
         for a, b in zip(outs["general"], outs[name]):
@@ -40,5 +42,5 @@ for c in range(cases):
                     worst = max(worst, float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2))))
     if not worst <= 2e-6:
         bad += 1
-        print("case", c, (size, ch, S, T, runlen), "FAILED rms", worst)
+        print("case", c, (size, ch, S, T, runlen, lpb, tiles), "FAILED rms", worst)
 print("soak_forms done: %d cases, failures: %d, %.1f s" % (cases, bad, time.time() - t0))
