@@ -1596,9 +1596,13 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
         // instructions per step instead of a slot * row-size product)
         const float2* xrow = X + (size_t)ring_slot(job.slot0, tb, ring) * P;
         const float2* const xend = X + (size_t)ring * P;
-        int left = nb;                                      // blocks not yet requested
+        int left = __builtin_amdgcn_readfirstlane(nb);      // blocks not yet requested (a scalar, and the compiler is told so)
         auto advance = [&]() {                              // past the tile's last block: stay on it (re-read, never used)
-            if (left > 1) { xrow += P; xrow = (xrow == xend) ? X : xrow; --left; }
+            const bool more_rows = left > 1;
+            const float2* nx = xrow + P;
+            nx = (nx == xend) ? X : nx;
+            xrow = more_rows ? nx : xrow;
+            left = max(left - 1, 1);
         };
         if constexpr (PIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G and the history have arrived: the count starts here
 #pragma unroll
@@ -1673,7 +1677,8 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
                 }
                 // unconditional: a store under a branch would not count in the compiler's vmcnt arithmetic
                 // and halve the prefetch depth
-                *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
+                if constexpr (PIN) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(sum), "s"(yrow) : "memory");   // (scalar row base + lane offset: no per-lane 64-bit pointer to advance)
+                else *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
                 yrow += P;
                 return t0 + u + 1 < nb;
             });
