@@ -12,7 +12,7 @@
 // that arrive while a batch is on the GPU queue up; whichever thread next sees a batch complete submits
 // everything queued as the next batch BEFORE it wakes anybody, so the GPU never waits for a sleeping thread.
 // Batches form exactly when there is contention and grow with it.  A SECOND batch goes to the GPU while one is
-// still running only when the queue holds at least as many blocks as that batch (two populations of files
+// still running only when the queue holds at least half as many blocks as that batch (two populations of files
 // taking turns: the GPU always has the next batch queued behind the current one); a trickle of small batches
 // beside a big one would only multiply the fixed cost of a launch chain.  Inside the engine a big batch is a
 // duplex pipeline over two launch lanes (folve_engine.h, fe_batch_submit): while one chunk's K3 writes
@@ -59,6 +59,9 @@ public:
     static bool Enabled();
     // Upper bound of requests per engine call.
     static void Configure(int max_batch);
+    // How full the queue must be for a second batch to leave while one is running: queued blocks >= quarters / 4 of the
+    // blocks in flight (default 2: half as many).
+    static void SetEarlyQuarters(int quarters);
 
     // Enqueue `frames` interleaved frames (ceil(frames / block) blocks, the last zero-padded) of stream `s`:
     // never waits for the GPU.  `in` and `out` must lie in page-locked memory bound to the stream and stay

@@ -167,6 +167,7 @@ void fh_batching_set(int enabled, int window_us, int max_batch) {
     folve::BatchScheduler::Configure(max_batch);
 }
 int fh_batching_enabled(void) { return folve::BatchScheduler::Enabled(); }
+void fh_batching_early_quarters(int quarters) { folve::BatchScheduler::SetEarlyQuarters(quarters); }
 int fh_batcher_process(fe_engine* engine, fe_stream* s, const float* in, int valid_frames, float* out) {
     return folve::BatchScheduler::ForEngine(engine)->Process(s, in, valid_frames, out, NULL);
 }

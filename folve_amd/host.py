@@ -38,6 +38,7 @@ HOST_SYMBOLS = [
     ("fh_pool_pooled_count", _i, [_vp, C.c_char_p]),
     ("fh_batching_set", None, [_i, _i, _i]),
     ("fh_batching_enabled", _i, []),
+    ("fh_batching_early_quarters", None, [_i]),
     ("fh_batcher_process", _i, [_vp, _vp, _vp, _i, _vp]),
     ("fh_batching_stats", None, [C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
     ("fh_batching_stats2", None, [C.POINTER(_ll)] * 5),

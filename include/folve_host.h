@@ -85,6 +85,7 @@ int fh_pool_pooled_count(fh_pool *pool, const char *config_path);
  * window_us is ignored (there is no collection window); max_batch < 0 keeps the current value. */
 void fh_batching_set(int enabled, int window_us, int max_batch);
 int fh_batching_enabled(void);
+void fh_batching_early_quarters(int quarters);   /* BatchScheduler::SetEarlyQuarters (experiments) */
 /* one block through the combiner of `engine` (what SoundProcessor::Process calls); returns the engine's status for the block */
 int fh_batcher_process(fe_engine *engine, fe_stream *s, const float *in, int valid_frames, float *out);
 /* totals over all GPUs since process start */

@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
         else if (a.rfind("pin=", 0) == 0) pin = atoi(a.c_str() + 4);
         else if (a.rfind("peaks=", 0) == 0) fh_device_peaks_set(atoi(a.c_str() + 6));
         else if (a.rfind("verify=", 0) == 0) verify = atoi(a.c_str() + 7);
+        else if (a.rfind("early=", 0) == 0) fh_batching_early_quarters(atoi(a.c_str() + 6));
         else if (a.rfind("tune=", 0) == 0) { tune_knob = atoi(a.c_str() + 5); tune_value = atoi(strchr(a.c_str(), ':') ? strchr(a.c_str(), ':') + 1 : "0"); }
     }
     fh_batching_set(batching, 0, 256);

@@ -58,3 +58,7 @@ for a, b, n, q, g in rows:
     d[0] += 1; d[1] += b - a; d[2] += g
 for n, (c, t, g) in sorted(names.items(), key=lambda kv: -kv[1][1]):
     print("  %-28s launches %5d  avg %8.1f us  avg grid %8.0f threads" % (n, c, t / c / 1e3, g / c))
+if len(sys.argv) > 2 and sys.argv[2] == "timeline":
+    t0 = rows[0][0]
+    for a, b, n, q, g in rows[:36]:
+        print("   q%-2d %-24s %8.1f -> %8.1f us  (%5.1f us, %6d threads)" % (q, n, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, g))
