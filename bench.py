@@ -682,7 +682,8 @@ def main():
             runs = []
             # (threads, combiner, run-ahead depth in blocks): depth 1 is the reference's one block per Process() call
             for nt, comb, ra in ((1, 1, 1), (1, 1, 64), (16, 1, 64), (64, 1, 1), (64, 1, 32), (64, 1, 64), (64, 1, 128), (64, 0, 1)):
-                nblk = 300 if ra == 1 else (20000 if nt == 1 else 4096 if nt <= 16 else 2048)
+                # long enough that the run-ahead ramp and the ragged end (threads finishing their last chunks) do not weigh
+                nblk = 300 if ra == 1 else (20000 if nt == 1 else 8192 if nt <= 16 else max(4096, 48 * ra))
                 r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), str(nblk), str(comb), "json",
                                     "run_ahead=%d" % ra],
                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=180)
