@@ -102,6 +102,7 @@ struct fe_engine {
     };
     PeakBuf pkb[4];
     int pkb_next = 0;
+    int duplex_chunk_mb = 0;             // FE_TUNE_DUPLEX_CHUNK_MB (0: 32)
     int duplex_out = 0;                  // 0 / 2: K3 -> device staging -> DMA out; 1: K3 stores into the callers' buffers
     hipEvent_t dx_free[2] = {};          // the batch that last used dx_stage[i] has finished
     bool dx_free_pending[2] = {};
@@ -680,7 +681,8 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     const bool duplex = submit_event && zero_copy && !e->tuning_single_lane && !e->profiling && e->lanes[1].st && n >= 2 &&
                         io_bytes >= ((size_t)32 << 20);
     if (duplex) {
-        const int chunks = (int)std::max<size_t>(2, std::min<size_t>({(size_t)kDuplexChunks, (size_t)n, io_bytes / ((size_t)32 << 20) + 1}));
+        const size_t chunk_bytes = (size_t)(e->duplex_chunk_mb > 0 ? e->duplex_chunk_mb : 32) << 20;       // PCM in + out per chunk
+        const int chunks = (int)std::max<size_t>(2, std::min<size_t>({(size_t)kDuplexChunks, (size_t)n, io_bytes / chunk_bytes + 1}));
         plan_duplex(streams, n, nframes, lane, chunks, &dplan, lane_of.data());
     }
     // A stream whose last call ran on another lane and is not known to have completed: its lane of this call
@@ -1525,6 +1527,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
         case FE_TUNE_DUPLEX_OUT:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "duplex out must be 0, 1 or 2");
             e->duplex_out = value;
+            return FE_OK;
+        case FE_TUNE_DUPLEX_CHUNK_MB:
+            if (value < 0 || value > 1024) return fail(FE_ERR_PARAM, "chunk size must be 0 .. 1024 MB");
+            e->duplex_chunk_mb = value;
             return FE_OK;
         case FE_TUNE_LANES:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "lanes must be 0 (automatic), 1 or 2");
