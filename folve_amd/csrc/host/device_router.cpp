@@ -91,10 +91,19 @@ int DeviceRouter::live_streams(int slot) const {
 
 // A cached filter that only the cache still holds (no stream uses it) and whose configuration file has changed or
 // is gone will never be asked for again under this mtime: let go of its spectra.
+bool DeviceRouter::StampsCurrent(const FileStamps& files) {
+    for (const auto& f : files) {
+        struct stat st;
+        if (stat(f.first.c_str(), &st) != 0 || st.st_mtime != f.second) return false;
+    }
+    return true;
+}
+
 void DeviceRouter::SweepLocked() {
     for (auto it = filters_.begin(); it != filters_.end();) {
         struct stat st;
-        const bool current = stat(it->first.first.c_str(), &st) == 0 && st.st_mtime == it->second.mtime;
+        const bool current = stat(it->first.first.c_str(), &st) == 0 && st.st_mtime == it->second.mtime &&
+                             StampsCurrent(it->second.files);
         if (!current && fe_filter_use_count(it->second.filter) == 1) {
             fe_filter_release(it->second.filter);
             it = filters_.erase(it);
@@ -105,7 +114,7 @@ void DeviceRouter::SweepLocked() {
 }
 
 fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_file, time_t mtime, int samplerate,
-                                   int channels, ZitaConfig* out_cfg) {
+                                   int channels, ZitaConfig* out_cfg, FileStamps* impulse_files) {
     const std::pair<std::string, fe_engine*> key(config_file, engine);
     {
         // The reference serialises Create() as a whole (sound-processor.cc:43); here only the bookkeeping is
@@ -115,13 +124,14 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
         for (;;) {
             auto it = filters_.find(key);
             if (it != filters_.end()) {
-                if (it->second.mtime == mtime) {
+                if (it->second.mtime == mtime && StampsCurrent(it->second.files)) {
                     *out_cfg = it->second.cfg;
                     out_cfg->config_file = NULL;
+                    if (impulse_files) *impulse_files = it->second.files;
                     fe_filter_retain(it->second.filter);
                     return it->second.filter;
                 }
-                fe_filter_release(it->second.filter);    // configuration file was touched: rebuild
+                fe_filter_release(it->second.filter);    // the configuration or one of its impulse files was touched: rebuild
                 filters_.erase(it);
             }
             if (!building_.count(key)) break;
@@ -142,6 +152,12 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
     zita.fsamp = samplerate;
     zita.ninp = channels;
     zita.nout = channels;
+    FileStamps files;
+    zita.on_impulse_user = &files;
+    zita.on_impulse_file = [](void* user, const char* path) {
+        struct stat st;
+        static_cast<FileStamps*>(user)->push_back(std::make_pair(std::string(path), stat(path, &st) == 0 ? st.st_mtime : (time_t)0));
+    };
     // As SoundProcessor::Create (sound-processor.cc:44-46): parse errors, or a
     // configuration that never defined a convolver, make creation fail.
     if (config(&zita, config_file.c_str()) != 0 || zita.filter == NULL) {
@@ -154,9 +170,12 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
         return NULL;
     }
     zita.config_file = NULL;
+    zita.on_impulse_file = NULL;
+    zita.on_impulse_user = NULL;
+    if (impulse_files) *impulse_files = files;
     {
         std::lock_guard<std::mutex> lk(mu_);
-        filters_[key] = CachedFilter{zita.filter, zita, mtime};
+        filters_[key] = CachedFilter{zita.filter, zita, mtime, files};
     }
     *out_cfg = zita;
     fe_filter_retain(zita.filter);

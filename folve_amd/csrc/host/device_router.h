@@ -46,12 +46,17 @@ public:
 
     // Parsed + committed filter for (config, mtime) on `engine`; NULL if the
     // configuration is broken.  The caller gets its own reference.
+    // *impulse_files (optional) receives the impulse files the configuration reads, with their modification times at
+    // the time the filter was built.
+    typedef std::vector<std::pair<std::string, time_t>> FileStamps;
     fe_filter* GetFilter(fe_engine* engine, const std::string& config_file, time_t mtime, int samplerate,
-                         int channels, ZitaConfig* out_cfg);
+                         int channels, ZitaConfig* out_cfg, FileStamps* impulse_files = NULL);
+    // True if every file still has the modification time recorded for it.
+    static bool StampsCurrent(const FileStamps& files);
 
 private:
     struct Slot { int device; fe_engine* engine; int live; };
-    struct CachedFilter { fe_filter* filter; ZitaConfig cfg; time_t mtime; };
+    struct CachedFilter { fe_filter* filter; ZitaConfig cfg; time_t mtime; FileStamps files; };
     void SweepLocked();                        // drop cached filters nobody uses whose configuration changed or vanished
     mutable std::mutex mu_;
     std::condition_variable built_;            // a filter that was being built has been cached (or has failed)

@@ -79,8 +79,9 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     memset(&zita, 0, sizeof(zita));
     // Parsing and the filter's FFTs happen once per (config, mtime, GPU); every
     // processor of that configuration shares the committed spectra.
+    DeviceRouter::FileStamps impulse_files;
     fe_filter* filter = DeviceRouter::Default()->GetFilter(engine, config_file, GetModificationTime(config_file),
-                                                           samplerate, channels, &zita);
+                                                           samplerate, channels, &zita, &impulse_files);
     if (!filter) return NULL;
     fe_stream* stream = NULL;
     // The stream's delay line is sized for the longest call this processor will make: its run-ahead depth
@@ -96,9 +97,9 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     if (NumaPlacement()) {
         // page-locked pages land where the allocating thread runs: next to the GPU that will read them
         ScopedDeviceAffinity near_gpu(fe_engine_device(engine));
-        return new SoundProcessor(zita, config_file, stream, run_depth);
+        return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files);
     }
-    return new SoundProcessor(zita, config_file, stream, run_depth);
+    return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files);
 }
 
 // The block buffer (`buffer_`, sound-processor.cc:62-63: fragm * max(ninp, nout) floats, reused in
@@ -124,8 +125,10 @@ static size_t ChunkFloats(const ZitaConfig& c, int depth) {
     return c.ninp == c.nout ? in : in + out;
 }
 
-SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream, int run_depth)
-    : zita_config_(config), config_file_(cfg), config_file_timestamp_(GetModificationTime(cfg)), stream_(stream),
+SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream, int run_depth,
+                               const std::vector<std::pair<std::string, time_t>>& impulse_files)
+    : zita_config_(config), config_file_(cfg), config_file_timestamp_(GetModificationTime(cfg)), impulse_files_(impulse_files),
+      stream_(stream),
       run_depth_(run_depth),
       buffer_floats_(static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)),
       arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth)),
@@ -341,8 +344,10 @@ void SoundProcessor::Process() {
     output_pos_ = 0;
 }
 
+// The reference compares the configuration file's timestamp and notes as a TODO that the *.wav files it mentions
+// should be checked as well (sound-processor.cc:129-133): they are, here.
 bool SoundProcessor::ConfigStillUpToDate() const {
-    return config_file_timestamp_ == GetModificationTime(config_file_);
+    return config_file_timestamp_ == GetModificationTime(config_file_) && DeviceRouter::StampsCurrent(impulse_files_);
 }
 
 void SoundProcessor::ResetMaxValues() {

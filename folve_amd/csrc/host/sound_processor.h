@@ -32,6 +32,8 @@
 #include <time.h>
 
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "zita_config.h"
 
@@ -128,7 +130,8 @@ private:
         float* peaks = nullptr;         // [blocks][2]: every block's signed maximum and maximum magnitude, from the GPU
         bool peaks_valid = false;       // ... filled in (else the block is scanned when it is handed out)
     };
-    SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth);
+    SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth,
+                   const std::vector<std::pair<std::string, time_t>>& impulse_files);
     void Process();
     bool ReadChunk(FrameSource* in, Chunk* c);    // true if the chunk holds at least one whole block
     void SubmitChunk(Chunk* c);
@@ -139,6 +142,7 @@ private:
     const ZitaConfig zita_config_;
     const std::string config_file_;
     const time_t config_file_timestamp_;
+    const std::vector<std::pair<std::string, time_t>> impulse_files_;   // what /impulse/read opened, and when it was last modified then
     fe_stream* const stream_;
 
     const int run_depth_;               // 1: no run-ahead

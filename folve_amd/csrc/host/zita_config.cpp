@@ -61,6 +61,7 @@ int readfile(ZitaConfig* cfg, const char* line, int lnum, const std::string& cdi
 
     const std::string path = (file[0] == '/') ? std::string(file) : cdir + "/" + file;
     ImpulseFile audio;
+    if (cfg->on_impulse_file) cfg->on_impulse_file(cfg->on_impulse_user, path.c_str());
     if (audio.open_read(path.c_str())) {
         Logf("%s:%d: Unable to open '%s' >%s<.", cfg->config_file, lnum, path.c_str(), cdir.c_str());
         return ERR_OTHER;

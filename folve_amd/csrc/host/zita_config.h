@@ -30,6 +30,12 @@ struct ZitaConfig {
     int ninp;
     int nout;
     int size;
+
+    // Not in the reference: called with the resolved path of every impulse file /impulse/read opens, so that the
+    // caller can implement the reference's own TODO — "this should as well check if any *.wav file mentioned is still
+    // the same timestamp" (sound-processor.cc:129-133).  NULL: nobody listens.
+    void (*on_impulse_file)(void* user, const char* path);
+    void* on_impulse_user;
 };
 
 enum { NOERR, ERR_OTHER, ERR_SYNTAX, ERR_PARAM, ERR_ALLOC, ERR_CANTCD, ERR_COMMAND, ERR_NOCONV, ERR_IONUM };

@@ -434,3 +434,28 @@ def test_a_blocks_bits_across_batch_sizes(oracle, tmp_path):
         y = first_of(n)
         assert oracle.rms(y - lone) <= 2e-6
     assert oracle.rms(lone - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+
+
+def test_a_touched_impulse_file_makes_processors_and_filters_stale(oracle, tmp_path):
+    """The reference's own TODO (sound-processor.cc:129-133: ConfigStillUpToDate "should as well check if any *.wav file
+    mentioned is still the same timestamp"): a processor whose impulse file changed is outdated — the pool drops it on
+    return and on checkout (processor-pool.cc:71-77,95-100) — and the router rebuilds the filter from the new file."""
+    d = make_pass_filter_dir(tmp_path, "lowpass")
+    conf = os.path.join(d, "filter-44100.conf")
+    wavs = [f for f in os.listdir(d) if f.lower().endswith(".wav")]
+    assert wavs
+    pool = H.ProcessorPool(3)
+    a, _ = pool.get_or_create(d, 44100, 2, 16)
+    b, _ = pool.get_or_create(d, 44100, 2, 16)
+    x = seeded_input(4, 2 * 8192 + 5, 2)
+    y = a.run(x)
+    pool.give_back(b)
+    assert pool.pooled_count(conf) == 1 and a.config_still_up_to_date()
+    time.sleep(1.1)
+    os.utime(os.path.join(d, wavs[0]), None)                          # the .conf itself is untouched
+    assert not a.config_still_up_to_date()
+    pool.give_back(a)                                                  # outdated: deleted, not pooled
+    assert pool.pooled_count(conf) == 1
+    fresh, _ = pool.get_or_create(d, 44100, 2, 16)                     # the pooled one is stale too: dropped, a new one built
+    assert fresh is not None and fresh.config_still_up_to_date() and pool.pooled_count(conf) == 0
+    assert np.array_equal(fresh.run(x), y)                             # same taps, rebuilt
