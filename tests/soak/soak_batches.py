@@ -1,6 +1,6 @@
 """Runs the large-batch parity test (tests/test_walkers_gpu.py: fast kernel forms against the oracle, the
 float64 convolution and the general kernels) over random shapes (dev aid; GPU).
-usage: python tools/soak_batches.py [cases]"""
+usage: python tests/soak/soak_batches.py [cases]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

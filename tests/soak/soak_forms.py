@@ -1,5 +1,5 @@
 """Random shapes through every K2 form and walker run length, each against the general kernels on the same
-input (dev aid; GPU).  usage: python tools/soak_forms.py [cases] [seed]"""
+input (dev aid; GPU).  usage: python tests/soak/soak_forms.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

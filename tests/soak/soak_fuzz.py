@@ -1,5 +1,5 @@
 """Runs the randomized call-pattern parity test (tests/test_fuzz_gpu.py) over many more seeds than the
-suite does (dev aid; GPU).  usage: python tools/soak_fuzz.py [last_seed]   — 5000 seeds take ~25 s."""
+suite does (dev aid; GPU).  usage: python tests/soak/soak_fuzz.py [last_seed]   — 5000 seeds take ~25 s."""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import folve_amd as fa

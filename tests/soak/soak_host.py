@@ -1,7 +1,7 @@
 """The drop-in host layer under random load (dev aid; GPU): rounds of file threads, each its own pooled SoundProcessor with
 a random run-ahead depth, files of random length drained in uneven pieces (half of the processors then reset and reused for
 a longer file), every output against the float64 convolution.
-usage: python tools/soak_host.py [rounds] [threads] [seed]"""
+usage: python tests/soak/soak_host.py [rounds] [threads] [seed]"""
 import os, sys, threading, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
