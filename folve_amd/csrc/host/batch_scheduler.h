@@ -20,7 +20,7 @@
 //
 // The threads that wait are the only workers: a thread whose request is in a batch nobody waits for yet
 // becomes that batch's waiter (fe_ticket_wait), settles every request in it, submits the next batch and
-// wakes the others.
+// wakes the others — with ONE notify_all: the requests that queue up together sleep on one gate and leave together.
 //
 // Results do not depend on the combiner being on or off beyond float32 rounding: a stream's arithmetic is
 // the same, but the K1/K2/K3 launch forms are chosen from the batch shape, and forms differ in summation
@@ -28,7 +28,7 @@
 // as a lone block and are bit-identical to it.
 #pragma once
 
-#include <condition_variable>   // (Request, in the .cpp, holds one per sleeping thread)
+#include <condition_variable>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -83,6 +83,7 @@ public:
 
 private:
     static const int kLanes = 2;
+    struct Gate { std::condition_variable cv; };   // what the threads of one queue generation sleep on
     struct Batch {
         std::vector<Request*> reqs;
         fe_ticket* ticket = nullptr;
@@ -99,6 +100,7 @@ private:
 
     std::mutex mu_;
     std::deque<Request*> queue_;
+    std::shared_ptr<Gate> next_gate_;           // the gate of the requests queueing up now
     std::vector<std::shared_ptr<Batch>> flying_;
     int lanes_busy_ = 0;                        // batches on the GPU + batches being submitted + lone synchronous calls
     long long queued_blocks_ = 0;               // blocks in queue_
