@@ -1,0 +1,312 @@
+// CPU test of the whole HOST layer — folve::SoundProcessor with run-ahead, ProcessorPool, DeviceRouter, the combiner, the
+// jconvolver loader — on a FAKE engine: this file implements the folve_engine.h entry points the host code calls with a
+// direct-form FIR on the CPU (tiny filters, block size 64), tickets that complete a little later, and is linked with the
+// real host sources.  It exists so that the block machine's ring / tail / ramp logic, the gapless hand-over and the pool
+// are exercised without a GPU and under ThreadSanitizer / AddressSanitizer (tests/test_host_cpu.py builds and runs it).
+// It is a test double for the C ABI, not a CPU path of the product: nothing in folve_amd/ links it.
+#include <assert.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../folve_amd/csrc/host/batch_scheduler.h"
+#include "../../folve_amd/csrc/host/processor_pool.h"
+#include "../../folve_amd/csrc/host/sound_processor.h"
+#include "../../include/folve_engine.h"
+
+// ---------------------------------------------------------------- the fake engine
+struct fe_engine { int device = 0; };
+struct fe_filter {
+    fe_engine* eng = nullptr;
+    std::atomic<int> refs{1};
+    int ninp = 0, nout = 0, size = 0, P = 0;
+    bool committed = false;
+    std::vector<std::vector<float>> taps;      // [inp * nout + out][size]
+    std::vector<int> link;
+};
+struct fe_stream {
+    fe_filter* f = nullptr;
+    int max_blocks = 1;
+    long long blocks_done = 0;
+    std::vector<std::vector<float>> hist;      // [inp][size]: the last `size` input samples, newest last
+    float peak_s = 0.f, peak_a = 0.f;
+    const char* bound = nullptr;
+    size_t bound_bytes = 0;
+};
+struct fe_ticket {
+    std::chrono::steady_clock::time_point ready;
+};
+
+namespace {
+thread_local std::string g_err;
+std::mutex g_engine_mu;                         // the fake computes at submit time, one call at a time (as e->mu serialises the real one)
+int fail(int rc, const char* m) { g_err = m; return rc; }
+
+// `frames` interleaved frames of stream s: y_o[n] = sum_i sum_t h_io[t] x_i[n - t], state carried in s->hist; whole blocks
+void fir(fe_stream* s, const float* in, long long frames, float* out, float* block_peaks) {
+    const fe_filter* f = s->f;
+    const int P = f->P;
+    const long long padded = ((frames + P - 1) / P) * P;      // the short last block is zero-padded: time advances by whole blocks
+    std::vector<float> y((size_t)frames * f->nout, 0.f);
+    std::vector<float> x((size_t)f->size + (size_t)padded);
+    for (int i = 0; i < f->ninp; ++i) {
+        std::copy(s->hist[(size_t)i].begin(), s->hist[(size_t)i].end(), x.begin());
+        for (long long n = 0; n < padded; ++n) x[(size_t)f->size + (size_t)n] = n < frames ? in[(size_t)n * f->ninp + i] : 0.f;
+        for (int o = 0; o < f->nout; ++o) {
+            int idx = i * f->nout + o;
+            for (int g = 0; g < 64 && f->link[(size_t)idx] >= 0; ++g) idx = f->link[(size_t)idx];
+            const std::vector<float>& h = f->taps[(size_t)idx];
+            if (h.empty()) continue;
+            for (long long n = 0; n < frames; ++n) {
+                double acc = 0.0;
+                for (int t = 0; t < f->size; ++t)
+                    if (h[(size_t)t] != 0.f) acc += (double)h[(size_t)t] * x[(size_t)f->size + (size_t)n - (size_t)t];
+                y[(size_t)n * f->nout + o] += (float)acc;
+            }
+        }
+        std::copy(x.end() - f->size, x.end(), s->hist[(size_t)i].begin());
+    }
+    const long long nb = padded / P;
+    for (long long b = 0; b < nb; ++b) {
+        float ps = 0.f, pa = 0.f;
+        for (long long n = b * P; n < std::min<long long>((b + 1) * P, frames); ++n)
+            for (int o = 0; o < f->nout; ++o) {
+                const float v = y[(size_t)n * f->nout + o];
+                ps = std::max(ps, v);
+                pa = std::max(pa, fabsf(v));
+            }
+        if (block_peaks) { block_peaks[2 * b] = ps; block_peaks[2 * b + 1] = pa; }
+        s->peak_s = std::max(s->peak_s, ps);
+        s->peak_a = std::max(s->peak_a, pa);
+    }
+    memcpy(out, y.data(), y.size() * sizeof(float));          // (in == out is allowed: y is a copy)
+    s->blocks_done += nb;
+}
+}  // namespace
+
+extern "C" {
+const char* fe_last_error(void) { return g_err.c_str(); }
+int fe_device_count(void) { return 1; }
+int fe_device_local_cpulist(int, char* buf, size_t size) { if (size) buf[0] = 0; return FE_ERR_UNSUPPORTED; }
+int fe_fragm_for_size(unsigned int maxsize) {
+    unsigned int fragm = FE_MAXQUANT;
+    while (fragm > FE_MINPART && fragm >= 2 * maxsize) fragm /= 2;
+    return (int)fragm;
+}
+int fe_engine_create(int device, void*, fe_engine** out) { *out = new fe_engine(); (*out)->device = device; return 0; }
+void fe_engine_destroy(fe_engine* e) { delete e; }
+int fe_engine_device(const fe_engine* e) { return e ? e->device : -1; }
+int fe_filter_create(fe_engine* e, int ninp, int nout, int maxsize, float, fe_filter** out) {
+    if (ninp < 1 || nout < 1 || maxsize < 1 || maxsize > 4096) return fail(FE_ERR_PARAM, "fake engine: tiny filters only");
+    fe_filter* f = new fe_filter();
+    f->eng = e; f->ninp = ninp; f->nout = nout; f->size = maxsize; f->P = fe_fragm_for_size((unsigned)maxsize);
+    f->taps.resize((size_t)ninp * nout);
+    f->link.assign((size_t)ninp * nout, -1);
+    *out = f;
+    return 0;
+}
+int fe_filter_add(fe_filter* f, int inp, int out, int step, const float* data, int ind0, int ind1) {
+    std::vector<float>& h = f->taps[(size_t)(inp * f->nout + out)];
+    if (f->link[(size_t)(inp * f->nout + out)] >= 0) return 0;
+    if (h.empty()) h.assign((size_t)f->size, 0.f);
+    for (int t = ind0; t < ind1 && t < f->size; ++t) h[(size_t)t] += data[(size_t)(t - ind0) * step];
+    return 0;
+}
+int fe_filter_link(fe_filter* f, int i1, int o1, int i2, int o2) {
+    if (f->taps[(size_t)(i1 * f->nout + o1)].empty() || !f->taps[(size_t)(i2 * f->nout + o2)].empty()) return 0;
+    f->link[(size_t)(i2 * f->nout + o2)] = i1 * f->nout + o1;
+    return 0;
+}
+int fe_filter_commit(fe_filter* f) { f->committed = true; return 0; }
+void fe_filter_retain(fe_filter* f) { if (f) f->refs.fetch_add(1); }
+void fe_filter_release(fe_filter* f) { if (f && f->refs.fetch_sub(1) == 1) delete f; }
+int fe_filter_use_count(const fe_filter* f) { return f ? f->refs.load() : 0; }
+int fe_stream_open(fe_filter* f, int max_blocks, fe_stream** out) {
+    fe_stream* s = new fe_stream();
+    s->f = f; s->max_blocks = max_blocks;
+    s->hist.assign((size_t)f->ninp, std::vector<float>((size_t)f->size, 0.f));
+    fe_filter_retain(f);
+    *out = s;
+    return 0;
+}
+int fe_host_alloc(size_t bytes, void** out) { *out = malloc(bytes); return *out ? 0 : FE_ERR_ALLOC; }
+void fe_host_free(void* p) { free(p); }
+int fe_stream_bind_host_buffer(fe_stream* s, void* buf, size_t bytes) { s->bound = (const char*)buf; s->bound_bytes = bytes; return 0; }
+int fe_stream_reset(fe_stream* s) {
+    for (auto& h : s->hist) std::fill(h.begin(), h.end(), 0.f);
+    s->blocks_done = 0; s->peak_s = s->peak_a = 0.f;
+    return 0;
+}
+int fe_stream_reset_peaks(fe_stream* s) { s->peak_s = s->peak_a = 0.f; return 0; }
+void fe_stream_close(fe_stream* s) { if (!s) return; fe_filter_release(s->f); delete s; }
+long long fe_stream_blocks_done(const fe_stream* s) { return s ? s->blocks_done : 0; }
+int fe_stream_block_size(const fe_stream* s) { return s ? s->f->P : 0; }
+int fe_stream_process(fe_stream* s, const float* in, int valid, float* out, float* ps, float* pa) {
+    if (!s || valid < 1 || valid > s->f->P) return fail(FE_ERR_PARAM, "bad block");
+    std::lock_guard<std::mutex> lk(g_engine_mu);
+    fir(s, in, valid, out, nullptr);
+    if (ps) *ps = s->peak_s;
+    if (pa) *pa = s->peak_a;
+    return 0;
+}
+int fe_batch_process(fe_stream* const* ss, int n, const float* const* in, const long long* nf, float* const* out, int) {
+    std::lock_guard<std::mutex> lk(g_engine_mu);
+    for (int i = 0; i < n; ++i) fir(ss[i], in[i], nf[i], out[i], nullptr);
+    return 0;
+}
+int fe_stream_process_blocks(fe_stream* s, const float* in, long long nframes, float* out) {
+    fe_stream* ss[1] = {s}; const float* ii[1] = {in}; float* oo[1] = {out}; long long nn[1] = {nframes};
+    return fe_batch_process(ss, 1, ii, nn, oo, 0);
+}
+int fe_batch_submit_peaks(fe_stream* const* ss, int n, const float* const* in, const long long* nf, float* const* out,
+                          float* const* block_peaks, fe_ticket** ticket) {
+    static std::atomic<long long> calls{0};
+    const long long k = calls.fetch_add(1);
+    for (int i = 0; i < n; ++i) {                             // the real engine refuses buffers outside the bound memory
+        const char* lo = ss[i]->bound;
+        if (!lo || (const char*)in[i] < lo || (const char*)in[i] + nf[i] * ss[i]->f->ninp * 4 > lo + ss[i]->bound_bytes)
+            return fail(FE_ERR_UNSUPPORTED, "buffer not bound");
+    }
+    if (k % 23 == 7) return fail(FE_ERR_DEVICE, "refused (fake)");     // nothing was enqueued
+    {
+        std::lock_guard<std::mutex> lk(g_engine_mu);
+        for (int i = 0; i < n; ++i) fir(ss[i], in[i], nf[i], out[i], block_peaks ? block_peaks[i] : nullptr);
+    }
+    fe_ticket* t = new fe_ticket();
+    t->ready = std::chrono::steady_clock::now() + std::chrono::microseconds(20 + (k * 13) % 150);
+    *ticket = t;
+    return 0;
+}
+int fe_ticket_done(fe_ticket* t) { return std::chrono::steady_clock::now() >= t->ready ? 1 : 0; }
+int fe_ticket_wait(fe_ticket* t) { std::this_thread::sleep_until(t->ready); delete t; return 0; }
+}
+
+// ---------------------------------------------------------------- the test
+namespace {
+struct MemSource : folve::FrameSource {
+    const std::vector<float>* d; size_t pos = 0; int ch; long long calls = 0;
+    MemSource(const std::vector<float>* v, int c) : d(v), ch(c) {}
+    int ReadFrames(float* dst, int frames) override {
+        const size_t have = d->size() / ch - pos, n = std::min<size_t>((size_t)frames, have);
+        memcpy(dst, d->data() + pos * ch, n * ch * sizeof(float));
+        pos += n; ++calls;
+        return (int)n;
+    }
+};
+struct MemSink : folve::FrameSink {
+    std::vector<float> d; int ch;
+    explicit MemSink(int c) : ch(c) {}
+    int WriteFrames(const float* src, int frames) override { d.insert(d.end(), src, src + (size_t)frames * ch); return frames; }
+};
+
+std::vector<float> direct(const std::vector<float>& x, int ch, const std::vector<std::vector<float>>& h /* per channel */) {
+    const size_t n = x.size() / ch;
+    std::vector<float> y(x.size(), 0.f);
+    for (int c = 0; c < ch; ++c)
+        for (size_t i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (size_t t = 0; t < h[(size_t)c].size() && t <= i; ++t) acc += (double)h[(size_t)c][t] * x[(i - t) * ch + c];
+            y[i * ch + c] = (float)acc;
+        }
+    return y;
+}
+double rms(const std::vector<float>& a, const std::vector<float>& b) {
+    if (a.size() != b.size()) return 1e9;
+    double e = 0.0;
+    for (size_t i = 0; i < a.size(); ++i) e += ((double)a[i] - b[i]) * ((double)a[i] - b[i]);
+    return sqrt(e / std::max<size_t>(1, a.size()));
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    const int nthreads = argc > 2 ? atoi(argv[2]) : 8, rounds = argc > 3 ? atoi(argv[3]) : 6;
+    // a 2-channel configuration of 20 taps (block size 64): two diracs per channel and a cross-free diagonal
+    const std::string conf = dir + "/filter-44100.conf";
+    {
+        FILE* f = fopen(conf.c_str(), "w");
+        fprintf(f, "/convolver/new 2 2 64 20\n/impulse/dirac 1 1 0.5 0\n/impulse/dirac 1 1 0.25 7\n/impulse/dirac 2 2 -0.75 3\n/impulse/dirac 2 2 0.125 19\n");
+        fclose(f);
+    }
+    std::vector<std::vector<float>> h(2, std::vector<float>(20, 0.f));
+    h[0][0] = 0.5f; h[0][7] = 0.25f; h[1][3] = -0.75f; h[1][19] = 0.125f;
+    std::atomic<long long> bad{0}, files{0};
+    folve::ProcessorPool pool(3);
+    const int P = 64;
+    for (int r = 0; r < rounds; ++r) {
+        const int depths[] = {1, 2, 3, 8, 32, 64};
+        folve::SoundProcessor::SetRunAhead(depths[r % 6]);
+        folve::SoundProcessor::SetDevicePeaks((r & 1) == 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) {
+            th.emplace_back([&, t, r] {
+                std::mt19937 rng((unsigned)(r * 100 + t));
+                std::string err;
+                folve::SoundProcessor* p = pool.GetOrCreate(dir, 44100, 2, 16, &err);
+                if (!p) { bad.fetch_add(1); fprintf(stderr, "GetOrCreate: %s\n", err.c_str()); return; }
+                // file A (ends in a short block most of the time) and, gapless, file B on the same processor
+                const size_t na = 1 + rng() % (40 * P), nb = (t & 1) ? P + rng() % (20 * P) : 0;   // (B at least a block: it completes A's last one)
+                std::vector<float> a(na * 2), b(nb * 2);
+                for (auto& v : a) v = (float)(rng() % 2001) / 1000.f - 1.f;
+                for (auto& v : b) v = (float)(rng() % 2001) / 1000.f - 1.f;
+                MemSource sa(&a, 2), sb(&b, 2);
+                MemSink oa(2), ob(2);
+                long long left = (long long)na;
+                while (left) {                                  // AddMoreSoundData (convolve-file-handler.cc:370-424)
+                    if (p->pending_writes() > 0) { p->WriteProcessed(&oa, p->pending_writes()); continue; }
+                    const int want = (int)std::min<long long>(P, left);            // what the reference's FillBuffer returns here
+                    const int got = p->FillBuffer(&sa);
+                    if (got != want) { bad.fetch_add(1); fprintf(stderr, "FillBuffer returned %d, the reference returns %d\n", got, want); return; }
+                    left -= got;
+                    if (p->is_input_buffer_complete() != (got == P)) { bad.fetch_add(1); fprintf(stderr, "is_input_buffer_complete\n"); return; }
+                    if (!left && !p->is_input_buffer_complete() && nb) {           // gapless: B tops the block up before A's last write
+                        const int top = p->FillBuffer(&sb);                        // (PassoverProcessor, cc:328-351)
+                        if (top != (int)std::min<size_t>((size_t)(P - got), nb)) { bad.fetch_add(1); fprintf(stderr, "top-up %d\n", top); return; }
+                    }
+                    const int cut = (int)(rng() % (unsigned)(got + 1));           // drain in two uneven pieces
+                    if (cut) p->WriteProcessed(&oa, cut);
+                    if (p->pending_writes() != P - cut && cut) { bad.fetch_add(1); fprintf(stderr, "pending_writes %d after %d\n", p->pending_writes(), cut); return; }
+                    if (got - cut) p->WriteProcessed(&oa, got - cut);
+                }
+                if (nb) {
+                    long long leftb = (long long)nb - (long long)sb.pos;
+                    while (leftb) {                             // B's AddMoreSoundData: first what the donor left processed (cc:373-376)
+                        if (p->pending_writes() > 0) { p->WriteProcessed(&ob, p->pending_writes()); continue; }
+                        const int got = p->FillBuffer(&sb);
+                        if (got != (int)std::min<long long>(P, leftb)) { bad.fetch_add(1); fprintf(stderr, "B: FillBuffer %d\n", got); return; }
+                        leftb -= got;
+                        p->WriteProcessed(&ob, got);
+                    }
+                    if (p->pending_writes() > 0 && p->is_input_buffer_complete()) p->WriteProcessed(&ob, p->pending_writes());
+                }
+                std::vector<float> both = a;
+                both.insert(both.end(), b.begin(), b.end());
+                std::vector<float> got = oa.d;
+                got.insert(got.end(), ob.d.begin(), ob.d.end());
+                const std::vector<float> ref = direct(both, 2, h);
+                const double e = rms(got, ref);
+                float mx = 0.f;
+                for (float v : got) mx = std::max(mx, v);
+                if (!(e <= 1e-6) || fabsf(p->max_output_value() - mx) > 1e-6f || !p->ok()) {
+                    bad.fetch_add(1);
+                    fprintf(stderr, "round %d thread %d: frames %zu + %zu, rms %g, peak %g vs %g, reads %lld\n", r, t, na, nb, e,
+                            p->max_output_value(), mx, sa.calls);
+                }
+                files.fetch_add(1);
+                pool.Return(p);
+            });
+        }
+        for (auto& x : th) x.join();
+    }
+    printf("{\"files\": %lld, \"bad\": %lld}\n", files.load(), bad.load());
+    return bad.load() == 0 && files.load() == (long long)nthreads * rounds ? 0 : 1;
+}

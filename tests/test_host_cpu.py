@@ -362,3 +362,36 @@ def test_combiner_ticket_path_under_thread_sanitizer(tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["bad"] == 0 and out["done"] == 24 * 300 == out["requests"]
     assert out["batches"] < out["requests"] and out["refused"] > 0 and out["max_tickets_in_flight"] <= 2
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_host_layer_on_a_fake_engine_under_sanitizers(tmp_path, sanitizer):
+    """The whole host layer without a GPU: the real SoundProcessor (run-ahead ring, tail, ramp, device or scanned peaks),
+    ProcessorPool, DeviceRouter, combiner and jconvolver loader linked against a fake engine that computes a direct-form FIR
+    (tests/compile/host_on_fake_engine.cpp).  8 file threads x 12 rounds of random-length files at run-ahead depths 1 .. 64,
+    half of them handed over gaplessly to a second file (convolve-file-handler.cc:328-351,370-424): every FillBuffer returns
+    what the reference's returns, pending_writes / is_input_buffer_complete agree, the output equals the convolution of the
+    concatenation, max_output_value the maximum of what was written — under ThreadSanitizer and AddressSanitizer + UBSan."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    host = os.path.join(ROOT, "folve_amd", "csrc", "host")
+    srcs = [os.path.join(ROOT, "tests", "compile", "host_on_fake_engine.cpp")] + [
+        os.path.join(host, n) for n in ("sound_processor.cpp", "processor_pool.cpp", "device_router.cpp", "batch_scheduler.cpp",
+                                        "numa_placement.cpp", "zita_config.cpp", "impulse_file.cpp", "sstring.cpp")]
+    exe = os.path.join(str(tmp_path), "host_fake")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizer, "-pthread", "-I" + os.path.join(ROOT, "include")] + srcs +
+                       ["-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("g++ without this sanitizer")
+    assert r.returncode == 0, r.stderr[-3000:]
+    work = os.path.join(str(tmp_path), "filters")
+    os.makedirs(work)
+    r = subprocess.run([exe, work, "8", "12"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out == {"files": 96, "bad": 0}
