@@ -707,6 +707,13 @@ def main():
                 multi["what"] = ("one process, %d file threads over %d GPUs through folve::DeviceRouter (streams to the least-loaded "
                                  "GPU, one combiner and one engine per GPU, no collective), run-ahead 64, threads and rings "
                                  "NUMA-placed next to their GPU" % (nt, ndev))
+            # every run against the bus: bytes each way per second, and as a fraction of what `end_to_end` moved in this run
+            e2e_gbs = (end_to_end or {}).get("pcie_GBs_each_way")
+            for r_ in runs:
+                if r_.get("blocks_per_s"):
+                    gbs = r_["blocks_per_s"] * P * C * 4 / 1e9
+                    r_["pcie_GBs_each_way"] = round(gbs, 2)
+                    r_["of_end_to_end"] = round(gbs / e2e_gbs, 3) if e2e_gbs else None
             drop_in = {"what": "N host threads, each a folve::SoundProcessor (page-locked ring, per-GPU combiner) pulling 8192-frame "
                                "stereo blocks as ConvolveFileHandler::AddMoreSoundData does: FillBuffer -> WriteProcessed over "
                                "sf_readf_float / sf_writef_float-shaped callbacks that copy every block in and out, K = %d; "
