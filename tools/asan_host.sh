@@ -13,4 +13,4 @@ done
 RT=$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)
 cd $R
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 LD_PRELOAD=$RT FOLVE_AMD_LIB=$B/libfolve_amd_asan.so \
-  python -m pytest tests/test_host_cpu.py -x -q -p no:cacheprovider "$@"
+  python -m pytest tests/test_host_cpu.py -x -q -p no:cacheprovider -k "not sanitizer" "$@"   # (the tests that build their own sanitizer binaries run in the plain suite)

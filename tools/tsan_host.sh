@@ -13,4 +13,4 @@ done
 RT=$($CLANG -print-file-name=libclang_rt.tsan-x86_64.so)
 cd $R
 TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0 LD_PRELOAD=$RT FOLVE_AMD_LIB=$B/libfolve_amd_tsan.so \
-  python -m pytest tests/test_host_cpu.py -x -q -p no:cacheprovider -k "combiner or pool" "$@"
+  python -m pytest tests/test_host_cpu.py -x -q -p no:cacheprovider -k "(combiner or pool) and not sanitizer" "$@"
