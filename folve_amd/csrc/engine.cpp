@@ -103,6 +103,7 @@ struct fe_engine {
     PeakBuf pkb[4];
     int pkb_next = 0;
     int duplex_chunk_mb = 0;             // FE_TUNE_DUPLEX_CHUNK_MB (0: 32)
+    int duplex_min_mb = 0;               // FE_TUNE_DUPLEX_MIN_MB (0: 32): smaller submitted batches keep the zero-copy kernels
     int duplex_out = 0;                  // 0 / 2: K3 -> device staging -> DMA out; 1: K3 stores into the callers' buffers
     hipEvent_t dx_free[2] = {};          // the batch that last used dx_stage[i] has finished
     bool dx_free_pending[2] = {};
@@ -679,7 +680,7 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     DuplexPlan dplan;
     const size_t io_bytes = (in_floats + out_floats) * sizeof(float);
     const bool duplex = submit_event && zero_copy && !e->tuning_single_lane && !e->profiling && e->lanes[1].st && n >= 2 &&
-                        io_bytes >= ((size_t)32 << 20);
+                        io_bytes >= ((size_t)(e->duplex_min_mb > 0 ? e->duplex_min_mb : 32) << 20);
     if (duplex) {
         const size_t chunk_bytes = (size_t)(e->duplex_chunk_mb > 0 ? e->duplex_chunk_mb : 32) << 20;       // PCM in + out per chunk
         const int chunks = (int)std::max<size_t>(2, std::min<size_t>({(size_t)kDuplexChunks, (size_t)n, io_bytes / chunk_bytes + 1}));
@@ -1527,6 +1528,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
         case FE_TUNE_DUPLEX_OUT:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "duplex out must be 0, 1 or 2");
             e->duplex_out = value;
+            return FE_OK;
+        case FE_TUNE_DUPLEX_MIN_MB:
+            if (value < 0 || value > 4096) return fail(FE_ERR_PARAM, "threshold must be 0 .. 4096 MB");
+            e->duplex_min_mb = value;
             return FE_OK;
         case FE_TUNE_DUPLEX_CHUNK_MB:
             if (value < 0 || value > 1024) return fail(FE_ERR_PARAM, "chunk size must be 0 .. 1024 MB");
