@@ -129,6 +129,7 @@ struct fe_engine {
     hipEvent_t dx_ev[16] = {};               // run_duplex: "K1 of chunk c has finished"
     // profiling
     int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none, < 0: every round)
+    int sync_in_flight = 0;              // synchronous zero-copy calls waiting (lock released) on lane 0
     bool tuning_single_lane = false;     // FE_TUNE_LANES = 1: every submitted batch on lane 0 (measurements)
     bool profiling = false;
     hipEvent_t pev[4] = {};
@@ -608,7 +609,7 @@ static unsigned long long host_now_ns() {
 int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* const* in,
                    const long long* nframes, float* const* out, int flags, unsigned int* peaks_out = nullptr,
                    hipEvent_t submit_event = nullptr, int lane = 0, long long* seq_out = nullptr,
-                   float* const* block_peaks = nullptr, fe_ticket* ticket = nullptr) {
+                   float* const* block_peaks = nullptr, fe_ticket* ticket = nullptr, std::unique_lock<std::mutex>* lk = nullptr) {
     Lane& L = e->lanes[lane];
     const hipStream_t st = L.st;
     bool device_ptrs = (flags & FE_DEVICE_PTRS) != 0;
@@ -655,8 +656,10 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         return fail(FE_ERR_UNSUPPORTED, "fe_batch_submit needs every buffer inside page-locked memory bound to its stream");
     struct HostIoScope {                 // tells the launch rounds of THIS call where the PCM lives
         fe_engine* e;
+        bool ended = false;
         HostIoScope(fe_engine* e_, bool on) : e(e_) { e->host_io = on; }
-        ~HostIoScope() { e->host_io = false; }
+        void end() { if (!ended) { e->host_io = false; ended = true; } }
+        ~HostIoScope() { end(); }
     } host_io_scope(e, zero_copy);
 
     std::vector<Item> all((size_t)n);
@@ -707,10 +710,14 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     // (whatever happens below, kernels of this call may have been enqueued: the streams belong to their lanes now)
     struct LaneScope {
         fe_engine* e; fe_stream* const* streams; int n; const int* lane_of; const long long* seqs;
-        ~LaneScope() {
+        bool ended = false;
+        void end() {
+            if (ended) return;
+            ended = true;
             for (int l = 0; l < kLanes; ++l) if (seqs[l]) e->lanes[l].submitted = seqs[l];
             for (int i = 0; i < n; ++i) { streams[i]->last_lane = lane_of[i]; streams[i]->last_seq = seqs[lane_of[i]]; }
         }
+        ~LaneScope() { end(); }
     } lane_scope{e, streams, n, lane_of.data(), seqs};
     if (!device_ptrs) {
         int rc = ensure_bytes(e, (void**)&e->stage_in, &e->stage_in_bytes, in_floats * sizeof(float));
@@ -805,6 +812,17 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
     if (!async) {
         if (zero_copy) {
             HOST_T(t_launched);
+            // The kernels are enqueued and nothing below touches the engine's shared buffers (a zero-copy call stages
+            // nothing): the engine's lock is let go for the wait, so that another thread can submit a batch — it goes to the
+            // other lane while this call is marked in flight on this one — instead of queueing behind a spinning caller.
+            struct Unlocked {
+                fe_engine* e; std::unique_lock<std::mutex>* lk;
+                Unlocked(fe_engine* e_, std::unique_lock<std::mutex>* lk_) : e(e_), lk(lk_) { if (lk) { e->sync_in_flight++; lk->unlock(); } }
+                ~Unlocked() { if (lk) { lk->lock(); e->sync_in_flight--; } }
+            };
+            host_io_scope.end();
+            lane_scope.end();
+            Unlocked unlocked(e, lk);
             // The latency path: poll for completion instead of sleeping on the runtime's interrupt
             // (the wake-up costs more than the kernels); bounded, then the ordinary wait.
             for (int spin = 0; spin < 4000; ++spin) {
@@ -817,13 +835,18 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
                     g_host_last_exit = t_done;
                 }
 #endif
-                if (q == hipSuccess) { (void)hipGetLastError(); L.done = seq; return FE_OK; }   // (clears the sticky "not ready" of earlier polls)
+                if (q == hipSuccess) { (void)hipGetLastError(); if (lk) lk->lock(); L.done = std::max(L.done, seq); if (lk) lk->unlock(); return FE_OK; }   // (clears the sticky "not ready" of earlier polls)
                 if (q != hipErrorNotReady) return fail(FE_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(q));
             }
             (void)hipGetLastError();
+            HIP_TRY(hipStreamSynchronize(st));
+            if (lk) lk->lock();
+            L.done = std::max(L.done, seq);
+            if (lk) lk->unlock();
+            return FE_OK;
         }
         HIP_TRY(hipStreamSynchronize(st));
-        L.done = seq;
+        L.done = std::max(L.done, seq);
     }
     return FE_OK;
 }
@@ -846,7 +869,8 @@ int pick_lane(fe_engine* e, int* lane) {
         HIP_TRY(hipEventCreateWithFlags(&e->lanes[1].xev, hipEventDisableTiming));
     }
     int l;
-    if (e->lanes[0].outstanding != e->lanes[1].outstanding) l = e->lanes[0].outstanding < e->lanes[1].outstanding ? 0 : 1;
+    if (e->sync_in_flight > 0) l = 1;    // lane 0 carries a synchronous call whose caller polls that stream: stay off it
+    else if (e->lanes[0].outstanding != e->lanes[1].outstanding) l = e->lanes[0].outstanding < e->lanes[1].outstanding ? 0 : 1;
     else { l = e->lane_toggle; e->lane_toggle ^= 1; }
     *lane = e->tuning_single_lane ? 0 : l;
     return FE_OK;
@@ -1370,8 +1394,8 @@ int fe_batch_process(fe_stream* const* streams, int n, const float* const* in, c
     if (n == 0) return FE_OK;
     if (!streams[0]) return fail(FE_ERR_PARAM, "null stream");
     fe_engine* e = streams[0]->eng;
-    std::lock_guard<std::mutex> lk(e->mu);
-    return process_locked(e, streams, n, in, nframes, out, flags);
+    std::unique_lock<std::mutex> lk(e->mu);
+    return process_locked(e, streams, n, in, nframes, out, flags, nullptr, nullptr, 0, nullptr, nullptr, nullptr, &lk);
 }
 
 int fe_batch_submit(fe_stream* const* streams, int n, const float* const* in, const long long* nframes,
@@ -1487,9 +1511,10 @@ int fe_stream_process(fe_stream* s, const float* in, int valid_frames, float* ou
     long long nn[1] = {valid_frames};
     unsigned int bits[2] = {0u, 0u};
     fe_engine* e = s->eng;
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     // one synchronisation for the block and its peaks
-    const int rc = process_locked(e, ss, 1, ii, nn, oo, FE_HOST_PTRS, (peak_signed || peak_abs) ? bits : nullptr);
+    const int rc = process_locked(e, ss, 1, ii, nn, oo, FE_HOST_PTRS, (peak_signed || peak_abs) ? bits : nullptr, nullptr, 0, nullptr,
+                                  nullptr, nullptr, &lk);
     if (rc) return rc;
     float v[2];
     memcpy(v, bits, sizeof(v));       // (zeros when no peak was asked for)
