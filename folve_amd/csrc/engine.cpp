@@ -1539,7 +1539,7 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             e->tuning.mac_form = value;
             return FE_OK;
         case FE_TUNE_FFT_FORM:
-            if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "FFT form must be 0, 1 or 2");
+            if (value < 0 || value > 3) return fail(FE_ERR_PARAM, "FFT form must be 0, 1, 2 or 3");
             e->tuning.fft_form = value;
             return FE_OK;
         case FE_TUNE_WALK_LPB:

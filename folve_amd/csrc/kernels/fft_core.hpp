@@ -229,6 +229,10 @@ FK_D void gst_v2(float2* p, v2f v) { *(FK_GLOBAL v2f*)p = v; }
 // Uniform base + 32-bit per-lane byte offset: the compiler emits the SGPR-base form
 // (global_load/store v, voffset, s[base:base+1]) — one VGPR per address instead of a 64-bit pair
 // and no per-lane 64-bit address arithmetic.  The base must be wave-uniform for that.
+FK_D float2 gld_u2(const void* base, unsigned off) {
+    const v2f v = *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)base + off);
+    return float2{v.x, v.y};
+}
 FK_D void gst_u2(void* base, unsigned off, float2 v) { *(FK_GLOBAL v2f*)((FK_GLOBAL char*)base + off) = v2f{v.x, v.y}; }
 // Loads and the 16-byte store carry the non-temporal hint (`nt`), for data this launch touches once and no later launch
 // finds in a cache anyway (the walkers' PCM, K3's read of the Y scratch): measured -3 % on K1, -3 % on

@@ -54,7 +54,7 @@ struct Tuning {
     int fwd_run = 0;        // K1 walker: consecutive blocks per workgroup
     int inv_run = 0;        // K3 walker: consecutive blocks per workgroup
     int mac_form = 0;       // K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk
-    int fft_form = 0;       // K1/K3: 1 general kernels only, 2 walkers whenever the shape allows (also small launches)
+    int fft_form = 0;       // K1/K3: 1 general kernels only, 2 walkers whenever the shape allows (also small launches), 3 no channel-pair walkers (many channels: the one-block-per-workgroup pair kernels)
     int walk_lpb = 0;       // K2 whole-call walk: lanes per bin (1, 2, 4) instead of the automatic choice
     int walk_tiles = 0;     // K2 whole-call walk: time tiles per call
     // set per call: the only descriptor of a one-stream launch, readable by the HOST.  The latency kernels then

@@ -441,9 +441,13 @@ __global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void forward_pair_kernel(c
 // other's LDS phases.  Every trip issues a fixed number of loads and stores (exact vmcnt waits).
 //   XL: stage B's last two passes exchange through the cross-lane transpose (fft_core.hpp)
 // ---------------------------------------------------------------------------
-template <int LOG2P, bool XL>
+//   MC: the stream has four or more (an even number of) channels; the workgroup owns the pair (2p, 2p+1) and finds it as
+//       8 adjacent bytes in every frame: two 8-byte loads per quad, plain ones (the other pairs' workgroups read the
+//       same lines: they meet in the XCD's L2), grid (8 * pairs, runs / 8, streams) when xl (as forward_kernel), else
+//       (runs, pairs, streams)
+template <int LOG2P, bool XL, bool MC = false>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
-                                                                                FilterDev f, int run) {
+                                                                                FilterDev f, int run, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
@@ -457,11 +461,14 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     __syncthreads();
     PH(6);                                                    // tables into LDS
     const StreamJob job = jobs[blockIdx.z];
-    const int b0 = blockIdx.x * run;
+    const int bx = (MC && xl) ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
+    const int c0 = !MC ? 0 : (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
+    const int cin = MC ? f.cin : 2;
+    const int b0 = bx * run;
     if (b0 >= job.nblocks) return;
     const int b1 = min(b0 + run, job.nblocks);
     const int tid = threadIdx.x;
-    const float* __restrict__ in = job.in;
+    const float* __restrict__ in = job.in + c0;
 
     // stage A rows k1 = 1, 2, 4 at column tid; split twiddle e^(-i*pi*k/P) at k = tid
     const float2 a1_ = f.twa[0 * N2 + tid], a2_ = f.twa[1 * N2 + tid], a4_ = f.twa[2 * N2 + tid];
@@ -472,9 +479,19 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     // two halves (one column each), the first before the second channel's stage B, the second after
     // it, and the second channel's samples wait as pairs (16 VGPRs), not as quads.
     float4 q[COLS][HR];
-    auto request_whole = [&](int c, const float* __restrict__ base) {
+    // this thread's frame pair inside a row of N2 pairs, in bytes
+    auto lane_off = [&](int t) { return MC ? (unsigned)t * 8u * (unsigned)cin : (unsigned)t * 16u; };
+    auto request_whole = [&](int c, const float* __restrict__ base, unsigned loff) {
 #pragma unroll
-        for (int h = 0; h < HR; ++h) q[c][h] = gld_u4_once(base + (size_t)(h * N2 + c * NT) * 4, (unsigned)tid * 16u);
+        for (int h = 0; h < HR; ++h) {
+            if constexpr (MC) {
+                const float* __restrict__ r = base + (size_t)(h * N2 + c * NT) * 2 * cin;
+                const float2 e = gld_u2(r, loff), o = gld_u2(r + cin, loff);
+                q[c][h] = float4{e.x, e.y, o.x, o.y};
+            } else {
+                q[c][h] = gld_u4_once(base + (size_t)(h * N2 + c * NT) * 4, loff);
+            }
+        }
     };
     auto request_partial = [&](int b) {                       // a stream's short last block
         const long long f0 = (long long)b * P;
@@ -484,14 +501,14 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
             for (int h = 0; h < HR; ++h) {
                 const long long fr = f0 + 2 * (h * N2 + tid + c * NT);
                 float4 v{0.f, 0.f, 0.f, 0.f};
-                if (fr < job.nframes) { v.x = gld(in + fr * 2); v.y = gld(in + fr * 2 + 1); }
-                if (fr + 1 < job.nframes) { v.z = gld(in + fr * 2 + 2); v.w = gld(in + fr * 2 + 3); }
+                if (fr < job.nframes) { v.x = gld(in + fr * cin); v.y = gld(in + fr * cin + 1); }
+                if (fr + 1 < job.nframes) { v.z = gld(in + (fr + 1) * cin); v.w = gld(in + (fr + 1) * cin + 1); }
                 q[c][h] = v;
             }
     };
     const int bw = (int)min((long long)b1, max((long long)b0, job.nframes / P));   // blocks [b0, bw) are whole
     PH(7);                                                    // job descriptor
-    if (b0 < bw) { request_whole(0, in + (size_t)b0 * P * 2); request_whole(1, in + (size_t)b0 * P * 2); }
+    if (b0 < bw) { request_whole(0, in + (size_t)b0 * P * cin, lane_off(tid)); request_whole(1, in + (size_t)b0 * P * cin, lane_off(tid)); }
     else request_partial(b0);
 
     // Opaque copies, taken inside the loop: everything derived from the four table values (the
@@ -523,10 +540,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
 #pragma unroll
         for (int c = 0; c < SplitGeom<LOG2P>::CNT; ++c) wsp[c] = c ? cmul_const(w0, kCos32[c], -kSin32[c]) : w0;
         const int slot = ring_slot(job.slot0, b, job.ring);
-        split_and_store<LOG2P>(s, wsp, t, job.fdl + ((size_t)ch * job.ring + slot) * P, 1.0f);
+        split_and_store<LOG2P>(s, wsp, t, job.fdl + ((size_t)(c0 + ch) * job.ring + slot) * P, 1.0f);
     };
     // One block, both channels.  NEXT: the block `next` is requested on the way.
-    auto do_block = [&]<bool NEXT>(std::bool_constant<NEXT>, int b, const float* __restrict__ next, int t) {
+    auto do_block = [&]<bool NEXT>(std::bool_constant<NEXT>, int b, const float* __restrict__ next, int t, unsigned loff) {
         float2 x[COLS][HR], x1[COLS][HR];
 #pragma unroll
         for (int c = 0; c < COLS; ++c)
@@ -549,14 +566,14 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
         PH(5);
         stage_a_ch(x1, t);
         __builtin_amdgcn_sched_barrier(0);                    // the loads are not hoisted into stage A (registers)
-        if constexpr (NEXT) request_whole(0, next);                     // flies during this channel's stage B and split
+        if constexpr (NEXT) request_whole(0, next, loff);               // flies during this channel's stage B and split
         PH(0);
         __syncthreads();
         PH(1);
         stage_b<LOG2P, false, XL>(s, twb_l, t);
         PH(2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NEXT) request_whole(1, next);                     // flies during the split
+        if constexpr (NEXT) request_whole(1, next, loff);               // flies during the split
         __syncthreads();
         PH(3);
         split(b, 1, t);
@@ -569,13 +586,15 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     for (int b = b0; b < bw; ++b) {
         int t = tid;
         asm volatile("" : "+v"(t));                           // keeps the address arithmetic inside the loop
-        // after the walk's last block the loads read this block again (cache-resident; the values are
-        // never used) so that every trip issues the same number of memory operations
-        do_block(std::true_type{}, b, in + (size_t)(b + 1 < bw ? b + 1 : b) * P * 2, t);
+        // Every trip issues the same number of memory operations.  After the walk's last block the loads go to the first
+        // frames of this block with a lane offset of zero — a handful of lines, the values never used — not over the
+        // whole block again: a short walk (two blocks of a lone many-channel stream) would read half its PCM twice.
+        const bool more = b + 1 < bw;
+        do_block(std::true_type{}, b, in + (size_t)(more ? b + 1 : b) * P * cin, t, more ? lane_off(t) : 0u);
     }
     if (bw < b1) {
         if (bw > b0) request_partial(bw);
-        do_block(std::false_type{}, bw, nullptr, tid);
+        do_block(std::false_type{}, bw, nullptr, tid, 0u);
     }
     PH_FLUSH(0);
     STAMP(2);
@@ -909,10 +928,14 @@ constexpr float kMidSin8[8] = {0.19509032201612825f, 0.55557023301960218f, 0.831
 // full lines — instead of two workgroups interleaving 4-byte stores.  Held to 128 VGPRs:
 // two workgroups share a CU and cover each other's barriers and memory waits.
 // ---------------------------------------------------------------------------
-template <int LOG2P, int COUT, bool XL>
+//   MC (with COUT = 2): the stream has four or more (an even number of) outputs; the workgroup owns the pair
+//       (2p, 2p+1) and every frame's pair leaves as one 8-byte store — plain stores: the pairs of a block meet in the
+//       XCD's L2 and reach HBM as whole lines.  grid (8 * pairs, runs / 8, streams) when xl, else (runs, pairs, streams)
+template <int LOG2P, int COUT, bool XL, bool MC = false>
 __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(const StreamJob* __restrict__ jobs,
                                                                                 FilterDev f,
-                                                                                const float2* __restrict__ Y, int run) {
+                                                                                const float2* __restrict__ Y, int run, int xl) {
+    static_assert(!MC || COUT == 2, "a channel pair");
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT;
@@ -928,7 +951,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
     __syncthreads();
     const StreamJob job = jobs[blockIdx.z];
-    const int b0 = blockIdx.x * run;
+    const int bx = (MC && xl) ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
+    const int o0 = !MC ? 0 : (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
+    const int cout = MC ? f.cout : COUT;
+    const int b0 = bx * run;
     if (b0 >= job.nblocks) return;
     const int b1 = min(b0 + run, job.nblocks);
     const int tid = threadIdx.x;
@@ -941,7 +967,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     StageATw<LOG2P> atw_b_ = load_stage_a_tw<LOG2P>(f.twa, cb);
     atw_a_.w[3] = atw_b_.w[3] = float2{1.f, 0.f};
 
-    auto row_of = [&](int b, int o) { return Y + ((size_t)job.yunit0 + (size_t)o * job.nblocks + b) * P; };
+    auto row_of = [&](int b, int o) { return Y + ((size_t)job.yunit0 + (size_t)(o0 + o) * job.nblocks + b) * P; };
     // The next Y row is requested in two halves (one column of the pair each): the first as soon as
     // the fold has consumed the current row — it flies during stages A and B —, the second after
     // stage B: 16 instead of 32 VGPRs in flight across the transform, which is what lets two
@@ -957,7 +983,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     };
     request_a(row_of(b0, 0));
     request_b(row_of(b0, 0));
-    float* __restrict__ out = job.out;
+    float* __restrict__ out = job.out + o0;
     float pk_s = 0.0f, pk_a = 0.0f;
     PH(7);                                                    // tables into LDS, job descriptor, first Y row requested
 
@@ -1045,17 +1071,24 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
                     if constexpr (COUT == 2) {
                         const float2 l = zl[c];
                         if constexpr (WHOLE) {
-                            gst_u4_once(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
+                            if constexpr (MC) {
+                                float* __restrict__ r = out + (size_t)(fb + 2 * c * NT) * cout;
+                                const unsigned toff = (unsigned)t * 8u * (unsigned)cout;
+                                gst_u2(r, toff, float2{l.x, z.x});                      // frame fb + 2q - P
+                                gst_u2(r + cout, toff, float2{l.y, z.y});               // and the next one
+                            } else {
+                                gst_u4_once(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
+                            }
                             pk_s = fmaxf(pk_s, fmaxf(fmaxf(l.x, l.y), fmaxf(z.x, z.y)));
                             pk_a = fmaxf(pk_a, fmaxf(fmaxf(fabsf(l.x), fabsf(l.y)), fmaxf(fabsf(z.x), fabsf(z.y))));
                         } else {
                             if (fr < job.nframes) {
-                                gst(out + fr * 2, l.x); gst(out + fr * 2 + 1, z.x);
+                                gst(out + fr * cout, l.x); gst(out + fr * cout + 1, z.x);
                                 pk_s = fmaxf(pk_s, fmaxf(l.x, z.x));
                                 pk_a = fmaxf(pk_a, fmaxf(fabsf(l.x), fabsf(z.x)));
                             }
                             if (fr + 1 < job.nframes) {
-                                gst(out + fr * 2 + 2, l.y); gst(out + fr * 2 + 3, z.y);
+                                gst(out + (fr + 1) * cout, l.y); gst(out + (fr + 1) * cout + 1, z.y);
                                 pk_s = fmaxf(pk_s, fmaxf(l.y, z.y));
                                 pk_a = fmaxf(pk_a, fmaxf(fabsf(l.y), fabsf(z.y)));
                             }
@@ -1811,7 +1844,7 @@ struct FwdLaunch {
                 // P = 8192: walk consecutive blocks
                 const int runlen = tn.fwd_run > 0 ? tn.fwd_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(WaveGeom<L>::NT);
-                hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jobs, f, runlen);
+                hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jobs, f, runlen, 0);
                 return hipGetLastError();
             } else if constexpr (L >= 9) {                // 2P >= 1024: the one-transform stereo form exists
                 if (f.twa2) {
@@ -1832,6 +1865,20 @@ struct FwdLaunch {
             }
         }
         const int xl = max_blocks >= 8 ? 1 : 0;               // XCD-local order of a block's channels (see forward_kernel)
+        if constexpr (L == 13) {
+            // many channels, enough (block, pair) units for every workgroup to walk at least two: the walker per channel
+            // pair — the next block's PCM flies during this one's transforms, two workgroups per CU
+            const int pairs = f.cin / 2;
+            if (tn.fft_form != 1 && tn.fft_form != 3 && pairs_ok && f.cin >= 4 && f.cin % 2 == 0 &&
+                (tn.fft_form == 2 || (long long)njobs * pairs * max_blocks >= 1024)) {
+                const int runlen = tn.fwd_run > 0 ? tn.fwd_run : auto_run(njobs * pairs, max_blocks);
+                const int runs = (max_blocks + runlen - 1) / runlen;
+                const int wxl = runs >= 8 ? 1 : 0;
+                const dim3 grid = wxl ? dim3(8 * pairs, (runs + 7) / 8, njobs) : dim3(runs, pairs, njobs);
+                hipLaunchKernelGGL((forward_walker_kernel<L, true, true>), grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, runlen, wxl);
+                return hipGetLastError();
+            }
+        }
         if (tn.fft_form != 1 && pairs_ok && f.cin >= 4 && f.cin % 2 == 0) {   // many channels: a workgroup per channel pair
             const dim3 grid = xl ? dim3(8 * (f.cin / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin / 2, njobs);
             hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, xl);
@@ -1864,8 +1911,19 @@ struct InvLaunch {
             if (fast) {
                 const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
-                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true>), grid, block, 0, st, jobs, f, Y, runlen);
-                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1, true>), grid, block, 0, st, jobs, f, Y, runlen);
+                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true>), grid, block, 0, st, jobs, f, Y, runlen, 0);
+                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1, true>), grid, block, 0, st, jobs, f, Y, runlen, 0);
+                return hipGetLastError();
+            }
+            // many outputs: the walker per output pair (see FwdLaunch)
+            const int pairs = f.cout / 2;
+            if (tn.fft_form != 1 && tn.fft_form != 3 && pairs_ok && f.cout >= 4 && f.cout % 2 == 0 &&
+                (tn.fft_form == 2 || (long long)njobs * pairs * max_blocks >= 1024)) {
+                const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs * pairs, max_blocks);
+                const int runs = (max_blocks + runlen - 1) / runlen;
+                const int wxl = runs >= 8 ? 1 : 0;
+                const dim3 grid = wxl ? dim3(8 * pairs, (runs + 7) / 8, njobs) : dim3(runs, pairs, njobs);
+                hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true, true>), grid, dim3(NT), 0, st, jobs, f, Y, runlen, wxl);
                 return hipGetLastError();
             }
         }

@@ -182,7 +182,7 @@ enum {
     FE_TUNE_INV_RUN = 1,   /* K3 walker: consecutive blocks per workgroup */
     FE_TUNE_MAC_FORM = 2,  /* K2: 1 general, 4 / 8 / 16 sliding window of that many outputs, 100 whole-call walk (also for
                               sparse filters, whose empty rows of G are zeros in memory) */
-    FE_TUNE_FFT_FORM = 3,  /* K1/K3: 1 general kernels only, 2 walkers whenever the shape allows */
+    FE_TUNE_FFT_FORM = 3,  /* K1/K3: 1 general kernels only, 2 walkers whenever the shape allows, 3 no channel-pair walkers */
     FE_TUNE_FAIL_NEXT = 4, /* fault injection: the n-th launch round of this engine from now fails with FE_ERR_DEVICE (1 = the next;
                               negative: every round until the knob is set to 0) */
     FE_TUNE_WALK_LPB = 6,  /* K2 whole-call walk: lanes per bin (1, 2, 4; the filter's rows of G are spread over them) */

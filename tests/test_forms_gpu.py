@@ -447,18 +447,61 @@ def test_channel_pair_kernels_match_the_per_channel_ones(tuned, oracle, channels
     xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
     more = [rng.uniform(-1, 1, (2 * P + 3, channels)).astype(np.float32) for _ in lens]
     outs = {}
-    for form in (0, 1):
+    for form in (3, 1):                                                 # 3: the pair kernels, never the pair walkers
         tuned.set_tuning(fft_form=form)
         st = [flt.open_stream(11) for _ in lens]
         outs[form] = (fa.batch_process(st, xs), fa.batch_process(st, more), [s_.peaks() for s_ in st])
     for s_ in range(len(lens)):
-        assert np.array_equal(outs[0][0][s_], outs[1][0][s_])
-        assert np.array_equal(outs[0][1][s_], outs[1][1][s_])
-        assert outs[0][2][s_] == outs[1][2][s_]
+        assert np.array_equal(outs[3][0][s_], outs[1][0][s_])
+        assert np.array_equal(outs[3][1][s_], outs[1][1][s_])
+        assert outs[3][2][s_] == outs[1][2][s_]
     sp.reset()
-    assert _rms(outs[0][0][1] - sp.run(xs[1])) <= TOL
+    assert _rms(outs[3][0][1] - sp.run(xs[1])) <= TOL
     y64 = oracle.linear_convolution_f64(xs[0], dense_taps(paths, size), channels)
-    assert _rms(outs[0][0][0] - y64) <= TOL
+    assert _rms(outs[3][0][0] - y64) <= TOL
+
+
+@pytest.mark.parametrize("channels,runlen,nblocks", [(4, 1, 5), (4, 2, 19), (8, 4, 11), (8, 2, 23), (6, 8, 19), (8, 32, 40)])
+def test_channel_pair_walkers(tuned, oracle, channels, runlen, nblocks):
+    """Streams of four or more channels at P = 8192: forward_walker<13, MC> / inverse_walker<13, 2, MC> — a workgroup
+    walks `runlen` consecutive blocks of one channel pair, 8-byte loads and stores at the frame stride — against the
+    general kernels, the float64 convolution and the reference restatement: both grid orders (8 or more runs: the
+    XCD-local one, with its empty trailing workgroups), walks that end inside a stream, the peeled short last block,
+    state carried into a second call, peaks."""
+    size = 20000                                                       # P = 8192, K = 3
+    rng = np.random.default_rng(channels * 10000 + runlen * 100 + nblocks)
+    paths = {}
+    for c in range(channels):
+        paths[(c, (c + 1) % channels)] = [(0, (rng.standard_normal(4000) * 0.05).astype(np.float32))]
+        if c % 3 == 0:
+            paths[(c, c)] = [(size // 2, (rng.standard_normal(size // 2) / np.sqrt(size)).astype(np.float32))]
+    sp, flt, _ = make_pair(tuned, oracle, channels, channels, size, paths)
+    P = flt.block_size
+    lens = [nblocks * P, nblocks * P - 4321, (nblocks - 1) * P - 7, (runlen + 1) * P]
+    xs = [rng.uniform(-1, 1, (n, channels)).astype(np.float32) for n in lens]
+    more = [rng.uniform(-1, 1, (2 * P + 9, channels)).astype(np.float32) for _ in lens]
+    hd = dense_taps(paths, size)
+
+    tuned.set_tuning(fft_form=2, fwd_run=runlen, inv_run=runlen)
+    walk = [flt.open_stream(nblocks) for _ in lens]
+    ys = fa.batch_process(walk, xs)
+    ys2 = fa.batch_process(walk, more)
+    tuned.set_tuning(fft_form=1)
+    gen = [flt.open_stream(nblocks) for _ in lens]
+    yg = fa.batch_process(gen, xs)
+    yg2 = fa.batch_process(gen, more)
+    for s in range(len(lens)):
+        assert _rms(ys[s] - yg[s]) <= 2e-6 and _rms(ys2[s] - yg2[s]) <= 2e-6, s
+        pw, pg = walk[s].peaks(), gen[s].peaks()
+        assert abs(pw[0] - pg[0]) <= 1e-5 and abs(pw[1] - pg[1]) <= 1e-5
+    for s in (0, 1):
+        y64 = oracle.linear_convolution_f64(xs[s], hd, channels)
+        assert _rms(ys[s] - y64) <= TOL and _rms(ys[s] - y64) / _rms(y64) <= TOL, s
+        both = np.concatenate([ys[s], ys2[s]])
+        pk = walk[s].peaks()
+        assert abs(pk[0] - max(0.0, float(both.max()))) <= 1e-6 and abs(pk[1] - float(np.abs(both).max())) <= 1e-6
+    sp.reset()
+    assert _rms(ys[1] - sp.run(xs[1])) <= TOL
 
 
 def test_block_peaks_of_a_submitted_batch(tuned, oracle):

@@ -1,4 +1,5 @@
-"""Where the FFT kernels spend their cycles (dev aid, cfg3 shape).
+"""Where the FFT kernels spend their cycles (dev aid; default: the cfg3 shape).
+    python tools/phase_trace.py [streams] [blocks per call] [steps] [channels] [taps]
 
 Needs the TRACE build:  make -C folve_amd/csrc TRACE=1   (libfolve_amd_trace.so)
 The instrumented kernels add up, over workgroups, the shader-clock cycles wave 0 spends in
@@ -17,18 +18,19 @@ from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS, FE_ASYNC
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-size, P = 262144, 8192
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+size, P = (int(sys.argv[5]) if len(sys.argv) > 5 else 262144), 8192
 ts = torch.cuda.Stream()
 eng = fa.Engine(0, ts.cuda_stream)
 rng = np.random.default_rng(3)
-flt = fa.Filter(eng, 2, 2, size)
-for c in range(2):
+flt = fa.Filter(eng, C, C, size)
+for c in range(C):
     h = rng.standard_normal(size).astype(np.float32); h /= np.linalg.norm(h)
     flt.add(c, c, h)
 flt.commit()
 streams = [flt.open_stream(T) for _ in range(S)]
 with torch.cuda.stream(ts):
-    xs = [torch.rand(T * P, 2, device="cuda") * 2 - 1 for _ in range(S)]
+    xs = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
     ys = [torch.empty_like(x) for x in xs]
 plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S, FE_DEVICE_PTRS | FE_ASYNC)
 L = capi.lib()
