@@ -256,7 +256,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     std::vector<Item*> owners;
     jobs.reserve(items.size());
     owners.reserve(items.size());
-    int yunits = 0, max_blocks = 0;
+    int yunits = 0, max_blocks = 0, max_ring = 0;
     bool in_pairs_ok = true, out_pairs_ok = true, want_block_peaks = false;
     for (Item& it : items) {
         if (it.left <= 0) continue;
@@ -277,6 +277,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         j.slot0 = s->slot0;
         j.yunit0 = yunits;
         j.ring = s->ring;
+        max_ring = std::max(max_ring, s->ring);
         yunits += j.nblocks * f->nout;
         max_blocks = std::max(max_blocks, j.nblocks);
         jobs.push_back(j);
@@ -326,6 +327,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     fk::Tuning tn = e->tuning;
     tn.host_io = e->host_io;
     tn.in_resident = e->in_resident;
+    tn.max_ring = max_ring;
     if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
     tn.one_job = (nj == 1 && dj == e->jobs_host[slot]) ? e->jobs_host[slot] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
@@ -1120,8 +1122,13 @@ int fe_filter_commit(fe_filter* f) {
 
     // every output with exactly one input path, and how dense the populated-row bitmaps are (K2's form choice)
     f->mac_shape.single_path = true;
-    for (int o = 0; o < f->nout; ++o)
-        if (out_first[(size_t)o + 1] - out_first[(size_t)o] > 1) f->mac_shape.single_path = false;
+    f->mac_shape.max_paths = 0;
+    f->mac_shape.ndata = f->ndata;
+    for (int o = 0; o < f->nout; ++o) {
+        const int n = out_first[(size_t)o + 1] - out_first[(size_t)o];
+        if (n > 1) f->mac_shape.single_path = false;
+        f->mac_shape.max_paths = std::max(f->mac_shape.max_paths, n);
+    }
     {
         long long rows = 0, pop = 0;
         for (int d : owners) {

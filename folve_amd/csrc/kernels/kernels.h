@@ -62,12 +62,15 @@ struct Tuning {
     // when the descriptors sit in page-locked memory (2 us at the start of each of the three kernels)
     const struct StreamJob* one_job = nullptr;
     bool host_io = false;   // set per call: PCM in and out are page-locked HOST memory (zero-copy single-block path)
+    int max_ring = 0;       // set per call: the longest FDL ring among the launch's streams (K2's per-lane offsets)
     bool in_resident = false;   // ... but the input has been copied into device memory already (big batches: DMA in, kernels write out)
 };
 
 // What the filter's populated-row bitmaps allow K2 to assume (computed once at commit).
 struct MacShape {
     bool single_path = false;   // every output has exactly one input path
+    int max_paths = 0;          // most input paths any output has
+    int ndata = 0;              // spectra sets of the filter
     bool dense = false;         // most rows of G are populated (skipping rows would save < 40 %)
 };
 

@@ -1546,11 +1546,19 @@ __device__ __forceinline__ float dpp_quad(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
-template <int KR, int D, bool PIN = false, int NACC = 6, int LPB = 1>
+//
+// Several PATHS per output (NP = 2 or 4: full filter matrices, e.g. a true-stereo reverb's four paths): the LPB lanes of
+// a bin's group are NP sets of LPP = LPB / NP lanes, one set per input path of the output — its own rows of G, its own
+// input channel's spectra (a per-lane byte offset on the uniform row base), its own head lane that loads; the hand-down
+// stays inside a set, and the group's partial sums add up to the output's spectrum exactly as above.  An output with
+// fewer than NP paths leaves the spare sets' G at zero.
+template <int KR, int D, bool PIN = false, int NACC = 6, int LPB = 1, int NP = 1>
 __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <= 128) ? 4 : (2 * (2 * KR + D) + 12 + (LPB > 1 ? 16 : 0) <= 168) ? 3 : 2) void mac_walk_kernel(
     const StreamJob* __restrict__ jobs, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
     constexpr int W = KR + D;
     static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per bin");
+    static_assert((NP == 1 || NP == 2 || NP == 4) && NP <= LPB, "paths per output");
+    constexpr int LPP = LPB / NP;                           // lanes per path
     const StreamJob job = jobs[blockIdx.z];
     const int o = blockIdx.y / tiles;
     const int tb = (blockIdx.y - o * tiles) * tile_len;     // first block of this workgroup's time tile
@@ -1559,19 +1567,27 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
     const int P = f.P, K = f.K, ring = job.ring;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int bin = tid / LPB, sub = tid % LPB;
-    const int jb = sub * KR;                                // this lane's first row of G
-    const bool head = sub == 0;                             // the lane of its group that takes the loaded element
+    const int pi = sub / LPP;                               // which of the output's paths this lane works for
+    const int jb = (sub % LPP) * KR;                        // this lane's first row of G
+    const bool head = sub % LPP == 0;                       // the lane of its set that takes the loaded element
     const unsigned voff = (unsigned)bin * 8u;               // this thread's bin inside any spectrum row
     const bool packed = bin == 0;
     const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
     const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * job.nblocks + tb;
     if (pe1 > pe0) {
-        const PathEntry pth = f.paths[pe0];
-        // row bases are wave-uniform (scalar registers); the per-lane part of every address is `voff`
-        const float2* __restrict__ Hd = f.H + (size_t)pth.data * K * P;
-        const float2* __restrict__ X = job.fdl + (size_t)pth.in_ch * ring * P;
+        const bool path_on = NP == 1 || pi < pe1 - pe0;
+        const PathEntry pth = f.paths[NP == 1 ? pe0 : pe0 + (path_on ? pi : 0)];
+        // row bases are wave-uniform (scalar registers); the per-lane part of every address is `voff` — plus, with
+        // several paths, the path's spectra set and input channel (the launcher checks that 32 bits hold them)
+        const float2* __restrict__ Hd = NP == 1 ? f.H + (size_t)pth.data * K * P : f.H;
+        const float2* __restrict__ X = NP == 1 ? job.fdl + (size_t)pth.in_ch * ring * P : job.fdl;
+        const unsigned voff_g = NP == 1 ? voff : voff + (unsigned)pth.data * (unsigned)K * (unsigned)P * 8u;
+        const unsigned voff_x = NP == 1 ? voff : voff + (unsigned)pth.in_ch * (unsigned)ring * (unsigned)P * 8u;
+        auto ldrow_g = [&](const float2* rowbase) -> v2f {
+            return *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)rowbase + voff_g);
+        };
         auto ldrow = [&](const float2* rowbase) -> v2f {
-            return *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)rowbase + voff);
+            return *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)rowbase + voff_x);
         };
         v2f g[KR], w[W];
         // Every load below is issued unconditionally (rows that do not exist are replaced by a valid
@@ -1582,13 +1598,13 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
         if constexpr (LPB == 1) {
             if (K == KR) {                                  // the common case (K = 32 partitions + 1): no selects
 #pragma unroll
-                for (int j = 0; j < KR; ++j) g[j] = ldrow(Hd + (size_t)j * P);
+                for (int j = 0; j < KR; ++j) g[j] = ldrow_g(Hd + (size_t)j * P);
 #pragma unroll
                 for (int j = 1; j < KR; ++j) w[W - j] = ldrow(X + (size_t)ring_slot(job.slot0, tb - j, ring) * P);
             } else {
 #pragma unroll
                 for (int j = 0; j < KR; ++j) {
-                    const v2f v = ldrow(Hd + (size_t)(j < K ? j : 0) * P);
+                    const v2f v = ldrow_g(Hd + (size_t)(j < K ? j : 0) * P);
                     g[j] = (j < K) ? v : v2f{0.f, 0.f};
                 }
 #pragma unroll
@@ -1603,13 +1619,13 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
             // frame) is loaded too: it is the first element handed down to the next lane.
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
-                const bool on = jb + j < K;
-                const v2f v = ldrow(Hd + (size_t)(on ? jb + j : 0) * P);
+                const bool on = path_on && jb + j < K;
+                const v2f v = ldrow_g(Hd + (size_t)(on ? jb + j : 0) * P);
                 g[j] = on ? v : v2f{0.f, 0.f};
             }
 #pragma unroll
             for (int j = 1; j <= KR; ++j) {
-                const bool on = jb + j < K;                 // (an element no row will ever meet is a zero)
+                const bool on = path_on && jb + j < K;      // (an element no row will ever meet is a zero)
                 const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, on ? tb - j - jb : tb, ring) * P);
                 w[W - j] = on ? v : v2f{0.f, 0.f};
             }
@@ -1622,7 +1638,7 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
         // its wait; the kernel must stay free of spills and copies of window registers (checked in the
         // disassembly: no v_mov of a window register inside the loop; `make check-isa` looks for scratch).
         auto issue = [&](v2f& dst, const float2* rowbase) {
-            if constexpr (PIN) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(rowbase) : "memory");
+            if constexpr (PIN) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff_x), "s"(rowbase) : "memory");
             else dst = ldrow(rowbase);
         };
         // the next row to request, as a pointer that wraps at the ring's end (a handful of scalar
@@ -1648,7 +1664,7 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
         // hipcc pads ten to thirteen s_nop between such a statement and an inline-asm MAC that reads the register
         // right after it (it cannot see what the asm does): with the wait one step ahead of the use the padding is gone.
         if constexpr (PIN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(D - 1) : "memory");
-        if constexpr (LPB > 1) {
+        if constexpr (LPP > 1) {
             // (the hand-down of block tb - KR: slot D of the neighbour, read before the loop's first issue re-uses it)
             const float hx = dpp_row_shr1(w[D].x), hy = dpp_row_shr1(w[D].y);
             w[0].x = head ? w[0].x : hx;
@@ -1673,7 +1689,7 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
                     constexpr int N = (D - 1) + (u < D - 1 ? u : D - 1);
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[(u + 1) % W]) : "n"(N) : "memory");
                 }
-                if constexpr (LPB > 1) {
+                if constexpr (LPP > 1) {
                     const float hx = dpp_row_shr1(w[(u + 1 + D) % W].x), hy = dpp_row_shr1(w[(u + 1 + D) % W].y);
                     w[(u + 1) % W].x = head ? w[(u + 1) % W].x : hx;
                     w[(u + 1) % W].y = head ? w[(u + 1) % W].y : hy;
@@ -2072,7 +2088,7 @@ void fill_fft_tables(int log2P, float2* dst, int off[4]) {
 // at least two wavefronts per SIMD: a batch of many streams takes one lane per bin, a lone stream spreads its filter
 // over the lanes of a group and its blocks over time tiles.
 namespace {
-struct WalkShape { int kr, lpb, tiles, tile_len; };
+struct WalkShape { int kr, lpb, tiles, tile_len, np; };
 // rows of G per lane for `lpb` lanes per bin: the smallest instantiated window that holds ceil(rows / lpb); 0: none
 int walk_rows_per_lane(int rows, int lpb) {
     const int need = (rows + lpb - 1) / lpb;
@@ -2081,15 +2097,18 @@ int walk_rows_per_lane(int rows, int lpb) {
     if (need <= 33) return 33;
     return 0;
 }
-bool choose_walk(const FilterDev& f, int njobs, int max_blocks, WalkShape* out) {
+// np: lanes sets per group, one per path of an output (1, 2 or 4)
+bool choose_walk(const FilterDev& f, int njobs, int max_blocks, int np, WalkShape* out) {
     const int rows = f.K;
     if (rows > 132 || f.P < 256) return false;
     const long long want = 2048;                               // wavefronts: two per SIMD
     // a time tile re-reads `rows` rows of history: no shorter than 32 blocks, nor than half the filter
     const int min_tile = rows / 2 > 32 ? rows / 2 : 32;
     out->kr = 0;
-    for (int lpb = 1; lpb <= 4; lpb *= 2) {                    // fewest lanes per bin first: least arithmetic overhead,
-        const int kr = walk_rows_per_lane(rows, lpb);          // widest rows per wavefront
+    out->np = np;
+    for (int lpb = np; lpb <= 4; lpb *= 2) {                   // fewest lanes per bin first: least arithmetic overhead,
+        int kr = walk_rows_per_lane(rows, lpb / np);           // widest rows per wavefront
+        if (kr == 9 && lpb == 2) kr = 17;                      // (the instantiated windows: 17 / 33 rows with two lanes, 9 / 17 / 33 otherwise)
         if (!kr) continue;
         const long long waves = (long long)njobs * f.cout * (f.P / 64) * lpb;
         int tiles = 1;
@@ -2102,10 +2121,10 @@ bool choose_walk(const FilterDev& f, int njobs, int max_blocks, WalkShape* out) 
     }
     return out->kr != 0;
 }
-template <int KR, int D, int LPB>
+template <int KR, int D, int LPB, int NP = 1>
 void launch_walk(const StreamJob* jobs, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, hipStream_t st) {
     dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
-    hipLaunchKernelGGL((mac_walk_kernel<KR, D, true, 6, LPB>), grid, block, 0, st, jobs, f, Y, w.tiles, w.tile_len);
+    hipLaunchKernelGGL((mac_walk_kernel<KR, D, true, 6, LPB, NP>), grid, block, 0, st, jobs, f, Y, w.tiles, w.tile_len);
 }
 }  // namespace
 
@@ -2114,9 +2133,15 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     const int P2 = f.P / 2;
     int form = tn.mac_form;
     WalkShape ws{};
-    const bool walk_ok = shape.single_path && choose_walk(f, njobs, max_blocks, &ws);
+    // one path per output, or up to four with a lane set each (their per-lane offsets must fit 32 bits)
+    const int np = shape.max_paths <= 1 ? 1 : shape.max_paths == 2 ? 2 : 4;
+    const bool paths_ok = shape.max_paths <= 1 ||
+                          (shape.max_paths <= 4 && (unsigned long long)f.cin * (unsigned)tn.max_ring * f.P * 8ull < (1ull << 32) &&
+                           (unsigned long long)shape.ndata * f.K * f.P * 8ull < (1ull << 32));
+    const bool walk_ok = paths_ok && choose_walk(f, njobs, max_blocks, np, &ws);
     if (tn.walk_lpb > 0 && walk_ok) {                           // tests: pin the lanes per bin / the time tiles
-        const int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) ? walk_rows_per_lane(f.K, tn.walk_lpb) : 0;
+        int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) && tn.walk_lpb >= np ? walk_rows_per_lane(f.K, tn.walk_lpb / np) : 0;
+        if (kr == 9 && tn.walk_lpb == 2) kr = 17;
         if (kr) { ws.lpb = tn.walk_lpb; ws.kr = kr; }
     }
     if (tn.walk_tiles > 0 && walk_ok) {
@@ -2133,7 +2158,17 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     if (form == 100) {
         // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
         // waves start together and read 2 KB of a row between them: DRAM locality)
-        if (ws.lpb == 1) {
+        if (ws.np == 2 && ws.lpb == 2) {
+            if (ws.kr == 17) launch_walk<17, 15, 2, 2>(jobs, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 2, 2>(jobs, njobs, f, Y, ws, st);
+        } else if (ws.np == 2) {
+            if (ws.kr == 17) launch_walk<17, 15, 4, 2>(jobs, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 4, 2>(jobs, njobs, f, Y, ws, st);
+        } else if (ws.np == 4) {
+            if (ws.kr == 9) launch_walk<9, 15, 4, 4>(jobs, njobs, f, Y, ws, st);
+            else if (ws.kr == 17) launch_walk<17, 15, 4, 4>(jobs, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 4, 4>(jobs, njobs, f, Y, ws, st);
+        } else if (ws.lpb == 1) {
             if (ws.kr == 9) launch_walk<9, 7, 1>(jobs, njobs, f, Y, ws, st);
             else if (ws.kr == 17) launch_walk<17, 7, 1>(jobs, njobs, f, Y, ws, st);
             else launch_walk<33, 7, 1>(jobs, njobs, f, Y, ws, st);

@@ -90,7 +90,7 @@ def test_walkers_at_every_run_length(tuned, oracle, runlen, channels):
     (262144, False),      # K = 32: 33 rows of G, mac_walk<33>
     (131072, False),      # K = 16: mac_walk<17>
     (65536, False),       # K = 8:  mac_walk<9>
-    (50000, True),        # two paths into one output: the walk does not apply, the pin falls back
+    (50000, True),        # two paths into one output: the walk with a lane set per path (mac_walk<17, 2 lanes, 2 paths>)
     (204800, False),      # K = 25 with a sparse path (echo-like): rows of zeros
 ])
 def test_mac_forms_agree(tuned, oracle, size, cross):
@@ -409,6 +409,59 @@ def test_mac_walk_lanes_per_bin_and_time_tiles(tuned, oracle, size, channels, lp
                 assert _rms(y1[s] - ref1[s]) <= 2e-6, (lpb, tiles, s)
                 assert _rms(y2[s] - ref2[s]) <= 2e-6, (lpb, tiles, s)
             assert _rms(y1[0] - y64) <= TOL and _rms(y1[0] - y64) / _rms(y64) <= TOL, (lpb, tiles)
+
+
+@pytest.mark.parametrize("case", ["2x2 K32", "2x2 K64", "4to2 K8", "4to2 K16", "4to2 K32", "ragged 3x3"])
+def test_mac_walk_with_several_paths_per_output(tuned, oracle, case):
+    """Full filter matrices (a true-stereo reverb's four paths; jconvolver's /impulse/read lines for every (input, output),
+    /root/reference/zita-config.cc:55-177): the whole-call walk with one lane set per path of an output — 2 or 4 sets,
+    each 1 or 2 lanes wide, an output with fewer paths than sets, one with none — against the general MAC kernel on the
+    same calls (state carried into a second call, time tiles) and the float64 convolution."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    def taps(n, scale=1.0):
+        return (rng.standard_normal(n) * scale / np.sqrt(n)).astype(np.float32)
+    if case.startswith("2x2"):
+        size = 262144 if case.endswith("K32") else 524288
+        cin = cout = 2
+        paths = {(i, o): [(0, taps(size, 1.0 if i == o else 0.3))] for i in range(2) for o in range(2)}
+        lpbs = (0, 4) if case.endswith("K32") else (0,)               # automatic; K32 also two lanes per path
+    elif case.startswith("4to2"):
+        size = {"K8": 65536, "K16": 131072, "K32": 262144}[case.split()[1]]
+        cin, cout = 4, 2
+        paths = {(i, 0): [(0, taps(size, 0.5))] for i in range(4)}
+        paths.update({(i, 1): [(i * 100, taps(size - 1000, 0.5))] for i in (0, 2, 3)})      # three paths: one set stays empty
+        lpbs = (0,)
+    else:
+        size, cin, cout = 100000, 3, 3
+        paths = {(0, 0): [(0, taps(size))], (2, 0): [(5, taps(size // 2, 0.2))], (1, 1): [(0, taps(size))]}   # output 2: silence
+        lpbs = (0, 4)
+    sp, flt, _ = make_pair(tuned, oracle, cin, cout, size, paths)
+    P, K = flt.block_size, flt.partitions
+    T = K + 9
+    S = 2
+    lens = [T * P - 777 * s for s in range(S)]
+    xs = [rng.uniform(-1, 1, (n, cin)).astype(np.float32) for n in lens]
+    more = [rng.uniform(-1, 1, (19 * P - 5, cin)).astype(np.float32) for _ in range(S)]
+    tuned.set_tuning(mac_form=1)
+    st = [flt.open_stream(T) for _ in range(S)]
+    ref1 = fa.batch_process(st, xs)
+    ref2 = fa.batch_process(st, more)
+    y64 = oracle.linear_convolution_f64(xs[1], dense_taps(paths, size), cout)
+    assert _rms(ref1[1] - y64) <= TOL
+    for lpb in lpbs:
+        for tiles in (1, 3):
+            tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_tiles=tiles)
+            st = [flt.open_stream(T) for _ in range(S)]
+            y1 = fa.batch_process(st, xs)
+            y2 = fa.batch_process(st, more)
+            for s_ in range(S):
+                assert _rms(y1[s_] - ref1[s_]) <= 2e-6, (lpb, tiles, s_)
+                assert _rms(y2[s_] - ref2[s_]) <= 2e-6, (lpb, tiles, s_)
+            assert _rms(y1[1] - y64) <= TOL and _rms(y1[1] - y64) / _rms(y64) <= TOL, (lpb, tiles)
+            if cout == 3:
+                assert not y1[0][:, 2].any()
+    sp.reset()
+    assert _rms(ref1[1] - sp.run(xs[1])) <= TOL
 
 
 def test_automatic_walk_shapes_for_one_stream_calls(tuned, oracle):
