@@ -457,9 +457,6 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     float2* const twb_l = s + G::LDS_ELEMS;
     PH_INIT();
     STAMP(1);
-    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
-    __syncthreads();
-    PH(6);                                                    // tables into LDS
     const StreamJob job = jobs[blockIdx.z];
     const int bx = (MC && xl) ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     const int c0 = !MC ? 0 : (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
@@ -510,6 +507,10 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     PH(7);                                                    // job descriptor
     if (b0 < bw) { request_whole(0, in + (size_t)b0 * P * cin, lane_off(tid)); request_whole(1, in + (size_t)b0 * P * cin, lane_off(tid)); }
     else request_partial(b0);
+    // the stage-B pass tables into LDS behind the first block's requests (cache hits that ride in with the PCM instead of
+    // ahead of it: a two-block walk of a lone stream is short enough to notice); first read after stage A's barrier
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
+    PH(6);                                                    // tables into LDS
 
     // Opaque copies, taken inside the loop: everything derived from the four table values (the
     // rotated twiddles, the products W^3, W^5 ..) is then recomputed per transform — a few dozen VALU
@@ -948,8 +949,6 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     float2* const twb_l = s + G::LDS_ELEMS;
     PH_INIT();
     STAMP(5);
-    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
-    __syncthreads();
     const StreamJob job = jobs[blockIdx.z];
     const int bx = (MC && xl) ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     const int o0 = !MC ? 0 : (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
@@ -983,6 +982,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     };
     request_a(row_of(b0, 0));
     request_b(row_of(b0, 0));
+    for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];   // behind the first row's requests (see forward_walker_kernel)
     float* __restrict__ out = job.out + o0;
     float pk_s = 0.0f, pk_a = 0.0f;
     PH(7);                                                    // tables into LDS, job descriptor, first Y row requested
