@@ -15,9 +15,14 @@ for c in range(cases):
     S = int(rng.integers(1, 7))
     T = int(rng.integers(1, 90)) if size <= 270000 else int(rng.integers(1, 200))
     flt = fa.Filter(eng, ch, ch, size)
+    matrix = ch > 1 and rng.random() < 0.4                  # several paths per output: the walk's lane sets (up to four)
     for k in range(ch):
-        n = int(rng.integers(1, size + 1))
-        flt.add(k, k, (rng.standard_normal(n) / np.sqrt(n)).astype(np.float32), int(rng.integers(0, size - n + 1)))
+        ins = [k]
+        if matrix:
+            ins = sorted(set(int(i) for i in rng.choice(ch, size=int(rng.integers(1, min(ch, 5) + 1)), replace=False)))
+        for i in ins:
+            n = int(rng.integers(1, size + 1))
+            flt.add(i, k, (rng.standard_normal(n) / np.sqrt(n * len(ins))).astype(np.float32), int(rng.integers(0, size - n + 1)))
     flt.commit()
     P = flt.block_size
     calls = []
@@ -42,5 +47,5 @@ for c in range(cases):
                     worst = max(worst, float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2))))
     if not worst <= 2e-6:
         bad += 1
-        print("case", c, (size, ch, S, T, runlen, lpb, tiles), "FAILED rms", worst)
+        print("case", c, (size, ch, S, T, runlen, lpb, tiles, matrix), "FAILED rms", worst)
 print("soak_forms done: %d cases, failures: %d, %.1f s" % (cases, bad, time.time() - t0))
