@@ -18,14 +18,18 @@ struct BatchScheduler::Request {
     long long blocks = 0;
     int rc = 0;
     std::string error;
-    State state = kQueued;                  // under mu_
+    // written under mu_; kDone is stored LAST (release) and may be read by the request's own thread without the lock:
+    // from then on the scheduler does not touch the request, and that thread may free it
+    std::atomic<int> state{kQueued};
     std::shared_ptr<Batch> batch;           // once taken out of the queue
     // Where its thread sleeps (in Wait): the gate of the queue generation it arrived in.  Requests that queue up together
     // leave together as one batch, so ONE notify_all on their gate wakes exactly that batch's threads when it completes
     // (22 separate wake-ups from the completing thread took 70 - 110 us of every round), and ONE notify_one picks the
-    // batch's waiter when it is submitted.
+    // batch's waiter when it is submitted.  A gate has its own mutex: the woken threads do not meet on mu_ — a thread whose
+    // request is settled never takes mu_ again for it (40 threads re-acquiring one mutex after every batch was most of the
+    // cost of a block with 64 and more one-block threads).
     std::shared_ptr<Gate> gate;
-    bool sleeping = false;
+    bool sleeping = false;                  // under mu_ (its own thread clears it only on the path that re-takes mu_)
 };
 
 namespace {
@@ -73,7 +77,46 @@ void BatchScheduler::ReleaseEngine(fe_engine* engine) {
     Schedulers().erase(engine);
 }
 
+// Wake the sleepers of a gate (mu_ held or not; lock order mu_ -> gate).  The epoch makes a wake-up that comes between a
+// thread's decision to sleep (under mu_) and its wait (under the gate's mutex) count.
+void BatchScheduler::WakeGate(Gate* g, bool all) {
+    {
+        std::lock_guard<std::mutex> gl(g->m);
+        ++g->epoch;
+    }
+    if (all) g->cv.notify_all();
+    else g->cv.notify_one();
+}
+
+// Called with mu_ held; sleeps on r's gate with mu_ released.  True: the request is settled and mu_ is NOT held (nothing
+// of the scheduler's is touched again for it); false: woken for something else (a batch needs a waiter, the queue may
+// move), mu_ held again.
+bool BatchScheduler::SleepOnGate(std::unique_lock<std::mutex>& lk, Request* r) {
+    const std::shared_ptr<Gate> g = r->gate;
+    unsigned long long seen;
+    {
+        std::lock_guard<std::mutex> gl(g->m);
+        seen = g->epoch;
+    }
+    r->sleeping = true;
+    lk.unlock();
+    {
+        std::unique_lock<std::mutex> gl(g->m);
+        g->cv.wait(gl, [&] { return g->epoch != seen; });
+    }
+    if (r->state.load(std::memory_order_acquire) == kDone) return true;
+    lk.lock();
+    r->sleeping = false;
+    return false;
+}
+
 BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, long long frames, float* out, float* block_peaks) {
+    std::unique_lock<std::mutex> lk(mu_);
+    return SubmitLocked(lk, s, in, frames, out, block_peaks);
+}
+
+BatchScheduler::Request* BatchScheduler::SubmitLocked(std::unique_lock<std::mutex>& lk, fe_stream* s, const float* in, long long frames,
+                                                      float* out, float* block_peaks) {
     Request* r = new Request();
     r->s = s;
     r->in = in;
@@ -82,7 +125,6 @@ BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, l
     r->peaks = block_peaks;
     const int P = fe_stream_block_size(s);
     r->blocks = P > 0 ? (frames + P - 1) / P : 0;
-    std::unique_lock<std::mutex> lk(mu_);
     stats_.requests++;
     stats_.blocks += r->blocks;
     if (!next_gate_) next_gate_ = std::make_shared<Gate>();
@@ -102,6 +144,7 @@ BatchScheduler::Request* BatchScheduler::Submit(fe_stream* s, const float* in, l
 }
 
 bool BatchScheduler::Ready(Request* r) {
+    if (r->state.load(std::memory_order_acquire) == kDone) return true;
     std::unique_lock<std::mutex> lk(mu_);
     if (r->state == kDone) return true;
     if (r->state == kFlying) {
@@ -115,7 +158,19 @@ bool BatchScheduler::Ready(Request* r) {
 }
 
 int BatchScheduler::Wait(Request* r, std::string* error, bool* peaks_filled) {
-    std::unique_lock<std::mutex> lk(mu_);
+    if (r->state.load(std::memory_order_acquire) != kDone) {
+        std::unique_lock<std::mutex> lk(mu_);
+        WaitLocked(lk, r);
+    }
+    const int rc = r->rc;
+    if (error) *error = r->error;
+    if (peaks_filled) *peaks_filled = r->peaks_filled;
+    delete r;
+    return rc;
+}
+
+// mu_ held on entry, released on return; the request is settled then.
+void BatchScheduler::WaitLocked(std::unique_lock<std::mutex>& lk, Request* r) {
     while (r->state != kDone) {
         if (r->state == kFlying) {
             const std::shared_ptr<Batch> b = r->batch;
@@ -128,10 +183,7 @@ int BatchScheduler::Wait(Request* r, std::string* error, bool* peaks_filled) {
                 for (const std::shared_ptr<Batch>& o : flying_)
                     if (o->ticket && !o->has_waiter) { other = o; break; }
                 if (other) { CompleteLocked(lk, other); continue; }
-                const std::shared_ptr<Gate> g = r->gate;
-                r->sleeping = true;
-                g->cv.wait(lk);
-                r->sleeping = false;
+                if (SleepOnGate(lk, r)) return;
             }
             continue;
         }
@@ -141,17 +193,9 @@ int BatchScheduler::Wait(Request* r, std::string* error, bool* peaks_filled) {
             if (b->ticket && !b->has_waiter) { help = b; break; }
         if (help) { CompleteLocked(lk, help); continue; }
         if (MayPumpLocked()) { PumpLocked(lk); continue; }
-        const std::shared_ptr<Gate> g = r->gate;
-        r->sleeping = true;
-        g->cv.wait(lk);
-        r->sleeping = false;
+        if (SleepOnGate(lk, r)) return;
     }
-    const int rc = r->rc;
-    if (error) *error = r->error;
-    if (peaks_filled) *peaks_filled = r->peaks_filled;
     lk.unlock();
-    delete r;
-    return rc;
 }
 
 int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, float* out, std::string* error) {
@@ -174,8 +218,13 @@ int BatchScheduler::Process(fe_stream* s, const float* in, int valid_frames, flo
             PumpLocked(lk);
             return rc;
         }
+        Request* r = SubmitLocked(lk, s, in, valid_frames, out, nullptr);
+        WaitLocked(lk, r);                    // (releases mu_)
+        const int rc = r->rc;
+        if (error) *error = r->error;
+        delete r;
+        return rc;
     }
-    return Wait(Submit(s, in, valid_frames, out), error);
 }
 
 // Wait for b's ticket (outside the lock), settle its requests, put the next batch on the GPU, then wake b's threads.
@@ -196,22 +245,16 @@ void BatchScheduler::CompleteLocked(std::unique_lock<std::mutex>& lk, const std:
     // Wake the batch's threads FIRST — one notify_all per gate, a single system call as a rule — and submit the next batch
     // while they are waking up: a woken thread needs 20 - 30 us to run again, the engine call below 40 - 60 us; done the
     // other way round every thread of the batch lost that engine call's time before it could queue its next block.
-    Gate* woken[4] = {nullptr, nullptr, nullptr, nullptr};       // (a batch's requests nearly always share one gate)
-    int nwoken = 0;
+    std::vector<std::shared_ptr<Gate>> gates;                     // (a batch's requests nearly always share one gate)
     for (Request* q : settled) {
         q->rc = rc;
         if (rc != 0) q->error = msg;
         q->peaks_filled = rc == 0 && q->peaks != nullptr;
-        q->state = kDone;                   // (a request is not touched by the scheduler after this: its thread may free it)
-        if (!q->sleeping) continue;
-        Gate* g = q->gate.get();
-        bool seen = false;
-        for (int i = 0; i < nwoken && i < 4; ++i) seen = seen || woken[i] == g;
-        if (seen) continue;
-        if (nwoken < 4) woken[nwoken] = g;
-        ++nwoken;
-        g->cv.notify_all();
+        if (q->sleeping && std::find(gates.begin(), gates.end(), q->gate) == gates.end()) gates.push_back(q->gate);
     }
+    // (a request is not touched by the scheduler after this store: its thread may see it without the lock and free it)
+    for (Request* q : settled) q->state.store(kDone, std::memory_order_release);
+    for (const std::shared_ptr<Gate>& g : gates) WakeGate(g.get(), true);
     PumpLocked(lk);                         // everything that queued up meanwhile leaves as the next batch
 }
 
@@ -288,16 +331,17 @@ void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
             b->ticket = ticket;
             flying_.push_back(b);
         } else {
-            for (Request* r : b->reqs) r->state = kDone;
+            std::vector<std::shared_ptr<Gate>> gates;
+            for (Request* r : b->reqs)
+                if (r->sleeping && std::find(gates.begin(), gates.end(), r->gate) == gates.end()) gates.push_back(r->gate);
+            for (Request* r : b->reqs) r->state.store(kDone, std::memory_order_release);    // settled (one by one, above)
+            b->reqs.clear();
             b->done = true;
             lanes_busy_--;
             flying_blocks_ -= b->blocks;
+            for (const std::shared_ptr<Gate>& g : gates) WakeGate(g.get(), true);
         }
-        if (rc != 0) {
-            for (Request* r : b->reqs)
-                if (r->sleeping) r->gate->cv.notify_all();    // settled (one by one, above)
-            b->reqs.clear();
-        } else {
+        if (rc == 0) {
             // ONE sleeping thread becomes the batch's waiter: one of its own, else one whose request is still queued
             // (it helps, Wait); the others sleep on until their request is settled.  If every thread is busy elsewhere
             // the batch is picked up by the first that comes to wait or to submit.
@@ -307,7 +351,7 @@ void BatchScheduler::PumpLocked(std::unique_lock<std::mutex>& lk) {
             if (!waker)
                 for (Request* r : queue_)
                     if (r->sleeping) { waker = r; break; }
-            if (waker) waker->gate->cv.notify_one();    // (whoever wakes on that gate finds a batch without a waiter: Wait)
+            if (waker) WakeGate(waker->gate.get(), false);    // (whoever wakes on that gate finds a batch without a waiter: Wait)
         }
     }
 }

@@ -83,7 +83,11 @@ public:
 
 private:
     static const int kLanes = 2;
-    struct Gate { std::condition_variable cv; };   // what the threads of one queue generation sleep on
+    struct Gate {                                   // what the threads of one queue generation sleep on
+        std::mutex m;
+        std::condition_variable cv;
+        unsigned long long epoch = 0;               // under m: counts the wake-up calls
+    };
     struct Batch {
         std::vector<Request*> reqs;
         fe_ticket* ticket = nullptr;
@@ -97,6 +101,10 @@ private:
     void PumpLocked(std::unique_lock<std::mutex>& lk);                    // queue -> batches while a lane is free
     void CompleteLocked(std::unique_lock<std::mutex>& lk, const std::shared_ptr<Batch>& b);   // wait for b's ticket, settle, pump
     void RunAlone(Request* r);                                            // synchronous engine call for one request
+    Request* SubmitLocked(std::unique_lock<std::mutex>& lk, fe_stream* s, const float* in, long long frames, float* out, float* block_peaks);
+    void WaitLocked(std::unique_lock<std::mutex>& lk, Request* r);        // returns with the lock released, the request settled
+    bool SleepOnGate(std::unique_lock<std::mutex>& lk, Request* r);
+    static void WakeGate(Gate* g, bool all);
 
     std::mutex mu_;
     std::deque<Request*> queue_;
