@@ -21,6 +21,8 @@
 // The threads that wait are the only workers: a thread whose request is in a batch nobody waits for yet
 // becomes that batch's waiter (fe_ticket_wait), settles every request in it, submits the next batch and
 // wakes the others — with ONE notify_all: the requests that queue up together sleep on one gate and leave together.
+// The gate has a mutex of its own and a settled request is visible to its thread without the scheduler's lock, so the
+// woken threads do not queue up on that lock (they did: 128 one-block threads got 57 k blocks/s, now 165 k).
 //
 // Results do not depend on the combiner being on or off beyond float32 rounding: a stream's arithmetic is
 // the same, but the K1/K2/K3 launch forms are chosen from the batch shape, and forms differ in summation
