@@ -465,18 +465,19 @@ def test_mac_walk_with_several_paths_per_output(tuned, oracle, case):
 
 
 def test_automatic_walk_shapes_for_one_stream_calls(tuned, oracle):
-    """What launch_mac picks by itself for cfg2's and cfg4's shapes at a 128-block call (one stream: lanes per bin and
-    time tiles so that the launch fills the chip) agrees with the general kernel."""
+    """What the launchers pick by themselves for cfg2's and cfg4's shapes at a 128-block call (one stream: K2's lanes per
+    bin and time tiles so that the launch fills the chip) and for cfg4's at the benchmarked 256 blocks (1 024 (block, pair)
+    units: K1 / K3 walk in channel-pair mode) agrees with the general kernels."""
     rng = np.random.default_rng(77)
-    for size, C in ((204800, 2), (524288, 8)):
+    for size, C, T in ((204800, 2, 128), (524288, 8, 128), (524288, 8, 256)):
         paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
         _, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
         P = flt.block_size
-        x = rng.uniform(-1, 1, (128 * P - 99, C)).astype(np.float32)
-        tuned.set_tuning(mac_form=0, walk_lpb=0, walk_tiles=0)
-        y_auto = flt.open_stream(128).process_blocks(x)
-        tuned.set_tuning(mac_form=1)
-        y_gen = flt.open_stream(128).process_blocks(x)
+        x = rng.uniform(-1, 1, (T * P - 99, C)).astype(np.float32)
+        tuned.set_tuning(mac_form=0, fft_form=0, walk_lpb=0, walk_tiles=0)
+        y_auto = flt.open_stream(T).process_blocks(x)
+        tuned.set_tuning(mac_form=1, fft_form=1)
+        y_gen = flt.open_stream(T).process_blocks(x)
         assert _rms(y_auto - y_gen) <= 2e-6
         c = C - 1
         y64 = oracle.linear_convolution_f64(x[:40 * P], {(c, c): dense_taps(paths, size)[(c, c)]}, C)[:, c]
