@@ -681,9 +681,9 @@ def main():
                     f.write("/impulse/read %d %d 2e-3 0 0 0 %d ir.wav\n" % (c + 1, c + 1, c + 1))
             runs = []
             # (threads, combiner, run-ahead depth in blocks): depth 1 is the reference's one block per Process() call
-            for nt, comb, ra in ((1, 1, 1), (1, 1, 64), (16, 1, 64), (64, 1, 1), (64, 1, 32), (64, 1, 64), (64, 1, 128), (64, 0, 1)):
+            for nt, comb, ra in ((1, 1, 1), (1, 1, 64), (16, 1, 64), (64, 1, 1), (128, 1, 1), (64, 1, 32), (64, 1, 64), (64, 1, 128), (64, 0, 1)):
                 # long enough that the run-ahead ramp and the ragged end (threads finishing their last chunks) do not weigh
-                nblk = 300 if ra == 1 else (20000 if nt == 1 else 8192 if nt <= 16 else max(4096, 48 * ra))
+                nblk = (300 if not comb else 2000) if ra == 1 else (20000 if nt == 1 else 8192 if nt <= 16 else max(4096, 48 * ra))
                 r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), str(nt), str(nblk), str(comb), "json",
                                     "run_ahead=%d" % ra],
                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=180)
