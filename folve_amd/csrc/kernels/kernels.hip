@@ -744,10 +744,31 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     const long long fb = (long long)b * P;
     float pk_s = 0.0f, pk_a = 0.0f;
     constexpr int OUTS = (P / 2 + NT - 1) / NT;
+    // Interleaved output of two or more channels, where the geometry allows: FRAME-MAJOR (see inverse_walker_kernel) — of
+    // every run of 2 * NT frames thread t takes frames t and t + NT, so that a store instruction's 64 four-byte pieces lie
+    // in 64 consecutive frames instead of every other frame of 128: half the write requests.
+    constexpr bool FM = (P / 2) % NT == 0 && NT % 2 == 0;
+    const float* sf = reinterpret_cast<const float*>(s);
 #pragma unroll
     for (int c = 0; c < OUTS; ++c) {
         const int q = P / 2 + tid + c * NT;                  // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
         if (q >= P) continue;
+        if (FM && !wide1) {
+            const int q0 = P / 2 + c * NT + (tid >> 1);
+            const float z0 = sf[2 * G::at(q0) + (tid & 1)], z1 = sf[2 * G::at(q0 + NT / 2) + (tid & 1)];
+            const long long fr = fb + 2 * c * NT + tid;
+            if (fr < job.nframes) {
+                gst(out + fr * cout + o, z0);
+                pk_s = fmaxf(pk_s, z0);
+                pk_a = fmaxf(pk_a, fabsf(z0));
+            }
+            if (fr + NT < job.nframes) {
+                gst(out + (fr + NT) * cout + o, z1);
+                pk_s = fmaxf(pk_s, z1);
+                pk_a = fmaxf(pk_a, fabsf(z1));
+            }
+            continue;
+        }
         const float2 z = s[G::at(q)];
         const long long fr = fb + 2 * q - P;
         if (wide1 && fr + 1 < job.nframes) {                 // mono: the pair is contiguous
@@ -876,21 +897,29 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(con
         stage_b<LOG2P, true>(s, twb_l, tid);
         __syncthreads();
         // ---- transposed read: consecutive lanes take consecutive output frames ----
+        // FRAME-MAJOR where the geometry allows (see inverse_walker_kernel): of every run of 2 * NT frames thread t takes
+        // frames t and t + NT — one float of element t / 2 and one of element t / 2 + NT / 2 of the run — so that a store
+        // instruction's 64 eight-byte pieces lie in 64 consecutive frames: half the write requests of the element-major
+        // order (frames 2t and 2t + 1), in which every instruction touches every other frame of 128.
+        constexpr bool FM = (P / 2) % NT == 0 && NT % 2 == 0;
+        const float* sf = reinterpret_cast<const float*>(s);
 #pragma unroll
         for (int c = 0; c < OUTS; ++c) {
             const int q = P / 2 + tid + c * NT;              // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
             if (q >= P) continue;
-            const float2 z = s[G::at(q)];
+            const int q0 = P / 2 + c * NT + (tid >> 1);
+            const float2 z = FM ? float2{sf[2 * G::at(q0) + (tid & 1)], sf[2 * G::at(q0 + NT / 2) + (tid & 1)]} : s[G::at(q)];
             if (h == 0) { first[c] = z; continue; }
-            const long long fr = fb + 2 * q - P;
-            const float2 e = float2{first[c].x, z.x}, o = float2{first[c].y, z.y};   // frames fr and fr + 1: (o0, o0 + 1)
+            const long long fr = FM ? fb + 2 * c * NT + tid : fb + 2 * q - P;
+            const long long fr2 = FM ? fr + NT : fr + 1;
+            const float2 e = float2{first[c].x, z.x}, o = float2{first[c].y, z.y};   // frames fr and fr2: (o0, o0 + 1)
             if (fr < job.nframes) {
                 gst(reinterpret_cast<float2*>(out + fr * cout), e);
                 pk_s = fmaxf(pk_s, fmaxf(e.x, e.y));
                 pk_a = fmaxf(pk_a, fmaxf(fabsf(e.x), fabsf(e.y)));
             }
-            if (fr + 1 < job.nframes) {
-                gst(reinterpret_cast<float2*>(out + (fr + 1) * cout), o);
+            if (fr2 < job.nframes) {
+                gst(reinterpret_cast<float2*>(out + fr2 * cout), o);
                 pk_s = fmaxf(pk_s, fmaxf(o.x, o.y));
                 pk_a = fmaxf(pk_a, fmaxf(fabsf(o.x), fabsf(o.y)));
             }
@@ -1059,23 +1088,38 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
             PH(4);
             // ---- transposed read: consecutive lanes take consecutive output frames ----
             const long long fb = (long long)b * P;
+            // This thread's two frames of the c-th run of 2 * NT frames: frames 2t and 2t + 1 (one complex element of the
+            // image), or — a whole block of a many-channel stream — FRAME-MAJOR: thread t takes frames t and t + NT, so
+            // that a store instruction's 64 eight-byte pieces lie in 64 CONSECUTIVE frames (2 KB, each 64-byte segment
+            // written twice by neighbouring lanes) instead of every other frame of 128 (4 KB, every segment once per
+            // instruction): half the write requests for the same bytes.  (Element q + 512 c + 256 j of the image lies
+            // 68 c + 34 j elements behind element q — rows of 8, 16 + 1 padding: constant offsets for the LDS reads;
+            // tests/host_fft_check.cpp holds the identity against WaveGeom<13>::at.)
+            auto take = [&](int c) -> float2 {
+                if constexpr (MC && WHOLE) {
+                    const float* sf = reinterpret_cast<const float*>(s) + (2 * G::at(P / 2 + (t >> 1)) + (t & 1));
+                    return float2{sf[2 * (68 * c)], sf[2 * (68 * c + 34)]};
+                } else {
+                    return s[G::at(P / 2 + t + c * NT)];
+                }
+            };
             if (COUT == 2 && o == 0) {
 #pragma unroll
-                for (int c = 0; c < OUTS; ++c) zl[c] = s[G::at(P / 2 + t + c * NT)];
+                for (int c = 0; c < OUTS; ++c) zl[c] = take(c);
             } else {
 #pragma unroll
                 for (int c = 0; c < OUTS; ++c) {
                     const int q = P / 2 + t + c * NT;         // z[q] = (y[2q], y[2q+1]); overlap-save keeps q >= P/2
-                    const float2 z = s[G::at(q)];
+                    const float2 z = take(c);
                     const long long fr = fb + 2 * q - P;
                     if constexpr (COUT == 2) {
                         const float2 l = zl[c];
                         if constexpr (WHOLE) {
                             if constexpr (MC) {
                                 float* __restrict__ r = out + (size_t)(fb + 2 * c * NT) * cout;
-                                const unsigned toff = (unsigned)t * 8u * (unsigned)cout;
-                                gst_u2(r, toff, float2{l.x, z.x});                      // frame fb + 2q - P
-                                gst_u2(r + cout, toff, float2{l.y, z.y});               // and the next one
+                                const unsigned toff = (unsigned)t * 4u * (unsigned)cout;
+                                gst_u2(r, toff, float2{l.x, z.x});                      // frame fb + 2 c NT + t
+                                gst_u2(r + NT * cout, toff, float2{l.y, z.y});          // and the one NT frames on
                             } else {
                                 gst_u4_once(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
                             }

@@ -45,6 +45,17 @@ int main() {
         for (int i = 0; i < p.n; ++i) prod *= p.r[i];
         if (prod != (1 << l) || p.n < 2 || p.n > 4) { std::printf("bad plan %d\n", l); return 2; }
     }
+    // the LDS image of the P = 8192 transform: element q + 512 c + 256 j lies 68 c + 34 j elements behind element q
+    // (the constant offsets of the K3 walker's frame-major read-out of many-channel blocks, kernels.hip)
+    {
+        // WaveGeom<13>::at restated (the struct itself is device-side): rows of N2 padded elements, element k in row k % N1
+        constexpr int N1 = 8, N2 = 1024, RS = fk::lds_elems(N2) + 32 / N1, P = 8192;
+        auto at = [&](int k) { return (k % N1) * RS + fk::phys(k / N1); };
+        for (int q = P / 2; q < P / 2 + 256; ++q)
+            for (int c = 0; c < 8; ++c)
+                for (int j = 0; j < 2; ++j)
+                    if (at(q + 512 * c + 256 * j) != at(q) + 68 * c + 34 * j) { std::printf("bad image offset %d %d %d\n", q, c, j); return 3; }
+    }
     std::printf("max_abs_err %.3e\n", w);
     return w < 2e-6 ? 0 : 1;
 }

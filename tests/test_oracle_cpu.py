@@ -172,7 +172,11 @@ def test_committed_traffic_table_is_consistent():
             assert abs(e["read"][role] + e["write"][role] - e["bytes"][role]) <= 2          # (each rounded to an integer)
         if blocks > 1:                                           # run-ahead launches: the fast forms
             channels = int(key.split("_")[3][1:])
-            fwd, inv = ("forward_walker_kernel", "inverse_walker_kernel") if channels <= 2 else ("forward_chpair_kernel", "inverse_chpair_kernel")
+            # the walkers: stereo, or (many channels, from 1 024 (block, pair) units on) in channel-pair mode
+            fwd, inv = ("forward_walker_kernel<13, true, false>", "inverse_walker_kernel<13, 2, true, false>") if channels <= 2 else \
+                       ("forward_walker_kernel<13, true, true>", "inverse_walker_kernel<13, 2, true, true>")
+            if e["profile"].startswith(("r02", "r03_", "r03b", "r03g")):      # (profiles taken before the template lists grew)
+                fwd, inv = "forward_", "inverse_"
             assert e["kernels"]["forward"].startswith(fwd)
             assert e["kernels"]["mac"].startswith(("mac_walk_kernel", "mac_slide_kernel"))
             assert e["kernels"]["inverse"].startswith(inv)
