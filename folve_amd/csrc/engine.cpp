@@ -312,9 +312,11 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     // PCM crosses the bus anyway) read their descriptors straight from the page-locked buffer — no upload
     // command in front of K1 (10 - 15 us of copy-engine latency per round); large ones upload them once
     // (thousands of workgroups should not each fetch a descriptor over the bus).
+    // A launch of ONE stream carries its descriptor among the kernel arguments (Tuning::one_job): nothing to upload, nothing
+    // to fetch.
     const fk::StreamJob* dj = e->jobs_dev[slot];
     const int nj = (int)jobs.size();
-    if ((long long)nj * max_blocks <= (e->host_io ? 256 : 16)) {
+    if (nj == 1 || (long long)nj * max_blocks <= (e->host_io ? 256 : 16)) {
         dj = e->jobs_host[slot];
     } else {
         HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
@@ -329,7 +331,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     tn.in_resident = e->in_resident;
     tn.max_ring = max_ring;
     if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
-    tn.one_job = (nj == 1 && dj == e->jobs_host[slot]) ? e->jobs_host[slot] : nullptr;
+    tn.one_job = nj == 1 ? e->jobs_host[slot] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (after_k1) HIP_TRY(hipEventRecord(after_k1, st));

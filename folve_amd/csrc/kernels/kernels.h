@@ -57,9 +57,10 @@ struct Tuning {
     int fft_form = 0;       // K1/K3: 1 general kernels only, 2 walkers whenever the shape allows (also small launches), 3 no channel-pair walkers (many channels: the one-block-per-workgroup pair kernels)
     int walk_lpb = 0;       // K2 whole-call walk: lanes per bin (1, 2, 4) instead of the automatic choice
     int walk_tiles = 0;     // K2 whole-call walk: time tiles per call
-    // set per call: the only descriptor of a one-stream launch, readable by the HOST.  The latency kernels then
-    // receive it by value among their arguments instead of fetching jobs[0] — a dependent read over the bus
-    // when the descriptors sit in page-locked memory (2 us at the start of each of the three kernels)
+    // set per call: the only descriptor of a one-stream launch, readable by the HOST.  Every kernel then receives it
+    // by value among its arguments instead of fetching jobs[0] — a dependent read over the bus when the descriptors
+    // sit in page-locked memory (2 us at the start of each of the three latency kernels), an upload in front of K1
+    // when they sit in device memory (9.5 us per multi-block call of one stream)
     const struct StreamJob* one_job = nullptr;
     bool host_io = false;   // set per call: PCM in and out are page-locked HOST memory (zero-copy single-block path)
     int max_ring = 0;       // set per call: the longest FDL ring among the launch's streams (K2's per-lane offsets)

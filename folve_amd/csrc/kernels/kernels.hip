@@ -68,6 +68,19 @@ __device__ unsigned int g_stamp_n;
 
 namespace {
 
+// Where a kernel finds its stream descriptors: an array indexed by blockIdx.z, or — a launch of ONE stream — the
+// descriptor itself, among the kernel arguments (Tuning::one_job).  A one-stream call then needs no upload in front of
+// K1 (a copy kernel of 3.6 us behind a 5.8 us dependency gap: 9.5 of the 68 us of a 256-block call of one stereo stream)
+// and the latency kernels no dependent read over the bus.
+struct JobRef {
+    const StreamJob* jobs;
+    StreamJob one;
+};
+__device__ __forceinline__ StreamJob fetch_job(const JobRef& r) { return r.jobs ? r.jobs[blockIdx.z] : r.one; }
+inline JobRef make_job_ref(const StreamJob* jobs, const Tuning& tn) {
+    return tn.one_job ? JobRef{nullptr, *tn.one_job} : JobRef{jobs, StreamJob{}};
+}
+
 // complex multiply-accumulate on two packed bins
 __device__ __forceinline__ void cmac2(float4& acc, const float4& x, const float4& h) {
     acc.x = fmaf(x.x, h.x, acc.x); acc.x = fmaf(-x.y, h.y, acc.x);
@@ -165,7 +178,7 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
 // Any channel count, unaligned PCM, short last block, any P.
 // ---------------------------------------------------------------------------
 template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const StreamJob* __restrict__ jobs,
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(JobRef jr,
                                                                       FilterDev f, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += G::NT) twb_l[i] = f.twb[i];
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     // xl: grid (8 * channels, blocks / 8, streams) — the channels of a block are dispatched together and, workgroup ids
     // going round the 8 XCDs, land on ONE XCD, so the strided reads of the same interleaved frames meet in its L2.
     // Calls of fewer than 8 blocks keep grid (blocks, channels, streams): that order would put them all on one XCD.
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_kernel(const Stre
 // samples in registers (only the lower half of z is data: 8 elements per thread and channel) and transforms one channel
 // after the other in the same LDS image.  grid (8 * pairs, blocks / 8, streams), as forward_kernel.
 template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f, int xl) {
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(JobRef jr, FilterDev f, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(con
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (b >= job.nblocks) return;
     const int c0 = (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void forward_chpair_kernel(con
 }
 
 template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(const StreamJob* __restrict__ jobs,
+__global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(JobRef jr,
                                                                                FilterDev f) {
     using G = WaveGeom<LOG2P + 1>;                        // geometry of the 2P-point transform
     constexpr int P = 1 << LOG2P, N = 2 * P;
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
     float2* const twb_l = s + G::LDS_ELEMS;               // stage-B tables ride into LDS beside the PCM loads
     STAMP(1);
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb2[i];
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
     const int tid = threadIdx.x;
@@ -353,8 +366,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P + 1>::NT) void forward_dual_kernel(c
 // once and sorting through LDS measured the same: the 64 KB take ~4.5 us over the bus either way).
 // ---------------------------------------------------------------------------
 template <int LOG2P, bool XL>
-__global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void forward_pair_kernel(const StreamJob* __restrict__ jobs,
-                                                                               StreamJob one, FilterDev f) {
+__global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void forward_pair_kernel(JobRef jr, FilterDev f) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
     constexpr int N1 = G::N1, N2 = G::N2, NT = G::NT, COLS = G::COLS;
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void forward_pair_kernel(c
     float2* const s = s2[half];
     float2* const twb_l = s + G::LDS_ELEMS;
     STAMP(1);
-    const StreamJob job = jobs ? jobs[blockIdx.z] : one;      // one: the descriptor by value (Tuning::one_job)
+    const StreamJob job = fetch_job(jr);      // one: the descriptor by value (Tuning::one_job)
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
     const float* __restrict__ in = job.in;
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void forward_pair_kernel(c
 //       same lines: they meet in the XCD's L2), grid (8 * pairs, runs / 8, streams) when xl (as forward_kernel), else
 //       (runs, pairs, streams)
 template <int LOG2P, bool XL, bool MC = false>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(const StreamJob* __restrict__ jobs,
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(JobRef jr,
                                                                                 FilterDev f, int run, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void forward_walker_kernel(
     float2* const twb_l = s + G::LDS_ELEMS;
     PH_INIT();
     STAMP(1);
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int bx = (MC && xl) ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     const int c0 = !MC ? 0 : (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
     const int cin = MC ? f.cin : 2;
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(256) void make_g_kernel(const float2* __restrict__ 
 // second read of Y.
 // ---------------------------------------------------------------------------
 template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const StreamJob* __restrict__ jobs,
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(JobRef jr,
                                                                       FilterDev f,
                                                                       const float2* __restrict__ Y, int xl) {
     using G = WaveGeom<LOG2P>;
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     // xl: grid (8 * channels, blocks / 8, streams), as forward_kernel: the 4-byte stores of a block's channels into the
     // same interleaved frames meet in one XCD's L2 instead of reaching HBM as partial lines at different times
     const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
@@ -809,7 +821,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_kernel(const Stre
 // first one's samples wait in registers, and every frame's pair leaves as one 8-byte store (half the store instructions
 // of the per-channel kernel, 8 of every 32 bytes of a line instead of 4).  grid (8 * pairs, blocks / 8, streams).
 template <int LOG2P>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(JobRef jr, FilterDev f,
                                                                              const float2* __restrict__ Y, int xl) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT) void inverse_chpair_kernel(con
     __shared__ float2 s[G::LDS_ELEMS + G::TWB];
     float2* const twb_l = s + G::LDS_ELEMS;
     for (int i = threadIdx.x; i < G::TWB; i += NT) twb_l[i] = f.twb[i];
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int b = xl ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (b >= job.nblocks) return;
     const int o0 = (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
@@ -962,7 +974,7 @@ constexpr float kMidSin8[8] = {0.19509032201612825f, 0.55557023301960218f, 0.831
 //       (2p, 2p+1) and every frame's pair leaves as one 8-byte store — plain stores: the pairs of a block meet in the
 //       XCD's L2 and reach HBM as whole lines.  grid (8 * pairs, runs / 8, streams) when xl, else (runs, pairs, streams)
 template <int LOG2P, int COUT, bool XL, bool MC = false>
-__global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(const StreamJob* __restrict__ jobs,
+__global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(JobRef jr,
                                                                                 FilterDev f,
                                                                                 const float2* __restrict__ Y, int run, int xl) {
     static_assert(!MC || COUT == 2, "a channel pair");
@@ -978,7 +990,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
     float2* const twb_l = s + G::LDS_ELEMS;
     PH_INIT();
     STAMP(5);
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int bx = (MC && xl) ? blockIdx.y * 8 + (blockIdx.x & 7) : blockIdx.x;
     const int o0 = !MC ? 0 : (xl ? blockIdx.x >> 3 : blockIdx.y) * 2;
     const int cout = MC ? f.cout : COUT;
@@ -1184,8 +1196,7 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
 // R samples from the other and stores whole (L0, R0, L1, R1) quads — half h the even / odd ones.
 // ---------------------------------------------------------------------------
 template <int LOG2P, bool XL>
-__global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void inverse_pair_kernel(const StreamJob* __restrict__ jobs,
-                                                                               StreamJob one, FilterDev f,
+__global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void inverse_pair_kernel(JobRef jr, FilterDev f,
                                                                                const float2* __restrict__ Y) {
     using G = WaveGeom<LOG2P>;
     constexpr int P = 1 << LOG2P;
@@ -1197,7 +1208,7 @@ __global__ __launch_bounds__(2 * WaveGeom<LOG2P>::NT) void inverse_pair_kernel(c
     float2* const s = s2[half];
     float2* const twb_l = s + G::LDS_ELEMS;
     STAMP(5);
-    const StreamJob job = jobs ? jobs[blockIdx.z] : one;
+    const StreamJob job = fetch_job(jr);
     const int b = blockIdx.x;
     if (b >= job.nblocks) return;
     const int ca = t, cb = (t == 0) ? N2 / 2 : N2 - t;
@@ -1345,9 +1356,9 @@ __device__ __forceinline__ void mac_packed_bin0(const StreamJob& job, const Filt
 // one (stream, output channel); X rows are streamed once per time tile.
 // ---------------------------------------------------------------------------
 template <int TT>
-__global__ __launch_bounds__(256) void mac_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+__global__ __launch_bounds__(256) void mac_kernel(JobRef jr, FilterDev f,
                                                   float2* __restrict__ Y, int tiles) {
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int o = blockIdx.y / tiles;
     const int t0 = (blockIdx.y - o * tiles) * TT;
     if (t0 >= job.nblocks) return;
@@ -1442,10 +1453,10 @@ __device__ __forceinline__ float4 vload(const float4* p) { return gld(p); }
 // Tiles with <= 32 accumulator/window floats per array are held to 128 VGPRs (four waves per
 // SIMD): the streamed loads need that much parallelism in flight.
 template <int TT, int NB, int D>
-__global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel(const StreamJob* __restrict__ jobs, FilterDev f,
+__global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel(JobRef jr, FilterDev f,
                                                         float2* __restrict__ Y, int tiles) {
     using V = typename BinVec<NB>::type;
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int o = blockIdx.y / tiles;
     const int tile = blockIdx.y - o * tiles;
     const int t0 = tile * TT;
@@ -1598,12 +1609,12 @@ __device__ __forceinline__ float dpp_quad(float v) {
 // fewer than NP paths leaves the spare sets' G at zero.
 template <int KR, int D, bool PIN = false, int NACC = 6, int LPB = 1, int NP = 1>
 __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <= 128) ? 4 : (2 * (2 * KR + D) + 12 + (LPB > 1 ? 16 : 0) <= 168) ? 3 : 2) void mac_walk_kernel(
-    const StreamJob* __restrict__ jobs, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
+    JobRef jr, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
     constexpr int W = KR + D;
     static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per bin");
     static_assert((NP == 1 || NP == 2 || NP == 4) && NP <= LPB, "paths per output");
     constexpr int LPP = LPB / NP;                           // lanes per path
-    const StreamJob job = jobs[blockIdx.z];
+    const StreamJob job = fetch_job(jr);
     const int o = blockIdx.y / tiles;
     const int tb = (blockIdx.y - o * tiles) * tile_len;     // first block of this workgroup's time tile
     if (tb >= job.nblocks) return;
@@ -1793,10 +1804,10 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
 //   one block per stream (nblocks == 1); bin 0 (packed DC / Nyquist) by wave reduction.
 // ---------------------------------------------------------------------------
 template <int U>
-__global__ __launch_bounds__(64) void mac_small_kernel(const StreamJob* __restrict__ jobs, StreamJob one, FilterDev f,
+__global__ __launch_bounds__(64) void mac_small_kernel(JobRef jr, FilterDev f,
                                                        float2* __restrict__ Y) {
     STAMP(3);
-    const StreamJob job = jobs ? jobs[blockIdx.z] : one;   // one: the descriptor by value (Tuning::one_job)
+    const StreamJob job = fetch_job(jr);   // one: the descriptor by value (Tuning::one_job)
     const int o = blockIdx.y;
     const int P = f.P, K = f.K, ring = job.ring;
     const int P2 = P >> 1;
@@ -1895,6 +1906,7 @@ struct FwdLaunch {
     // pairs_ok: every stream's PCM pointer is 16-byte aligned (stereo frames loaded as quads / pairs)
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
                           const Tuning& tn, hipStream_t st) {
+        const JobRef jr = make_job_ref(jobs, tn);
         // Stereo fast forms, for launches that fill the chip (below that the per-channel kernel's
         // twice as many, half as long workgroups finish sooner).
         const bool fast = tn.fft_form != 1 && f.cin == 2 && pairs_ok &&
@@ -1904,12 +1916,12 @@ struct FwdLaunch {
                 // P = 8192: walk consecutive blocks
                 const int runlen = tn.fwd_run > 0 ? tn.fwd_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(WaveGeom<L>::NT);
-                hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jobs, f, runlen, 0);
+                hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jr, f, runlen, 0);
                 return hipGetLastError();
             } else if constexpr (L >= 9) {                // 2P >= 1024: the one-transform stereo form exists
                 if (f.twa2) {
                     dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
-                    hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jobs, f);
+                    hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jr, f);
                     return hipGetLastError();
                 }
             }
@@ -1919,8 +1931,7 @@ struct FwdLaunch {
             // transforms at once (one workgroup per CU: latency is all that counts here)
             if (tn.host_io && !tn.in_resident && tn.fft_form == 0 && f.cin == 2 && pairs_ok && (long long)njobs * max_blocks <= 64) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * WaveGeom<L>::NT);
-                if (tn.one_job) hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f);
-                else hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, jobs, StreamJob{}, f);
+                hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, jr, f);
                 return hipGetLastError();
             }
         }
@@ -1935,17 +1946,17 @@ struct FwdLaunch {
                 const int runs = (max_blocks + runlen - 1) / runlen;
                 const int wxl = runs >= 8 ? 1 : 0;
                 const dim3 grid = wxl ? dim3(8 * pairs, (runs + 7) / 8, njobs) : dim3(runs, pairs, njobs);
-                hipLaunchKernelGGL((forward_walker_kernel<L, true, true>), grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, runlen, wxl);
+                hipLaunchKernelGGL((forward_walker_kernel<L, true, true>), grid, dim3(WaveGeom<L>::NT), 0, st, jr, f, runlen, wxl);
                 return hipGetLastError();
             }
         }
         if (tn.fft_form != 1 && pairs_ok && f.cin >= 4 && f.cin % 2 == 0) {   // many channels: a workgroup per channel pair
             const dim3 grid = xl ? dim3(8 * (f.cin / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin / 2, njobs);
-            hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, xl);
+            hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jr, f, xl);
             return hipGetLastError();
         }
         const dim3 grid = xl ? dim3(8 * f.cin, (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin, njobs);
-        hipLaunchKernelGGL(forward_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jobs, f, xl);
+        hipLaunchKernelGGL(forward_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jr, f, xl);
         return hipGetLastError();
     }
 };
@@ -1954,6 +1965,7 @@ struct InvLaunch {
     // pairs_ok: every stream's output pointer is 16-byte aligned
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, const float2* Y,
                           bool pairs_ok, const Tuning& tn, hipStream_t st) {
+        const JobRef jr = make_job_ref(jobs, tn);
         constexpr int NT = WaveGeom<L>::NT;
         if constexpr (L == 13) {      // P = 8192 (every filter longer than 4096 taps): one column pair per thread
             // The walker halves the workgroup count; keep the general kernel while that would leave CUs idle.
@@ -1962,8 +1974,7 @@ struct InvLaunch {
             // the one-block call from host memory, stereo: both outputs at once in one 1024-thread workgroup
             if (tn.host_io && tn.fft_form == 0 && pairs_ok && f.cout == 2 && (long long)njobs * max_blocks <= 64) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * NT);
-                if (tn.one_job) hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f, Y);
-                else hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, jobs, StreamJob{}, f, Y);
+                hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, jr, f, Y);
                 return hipGetLastError();
             }
             const bool fast = tn.fft_form != 1 && pairs_ok && (f.cout == 1 || f.cout == 2) &&
@@ -1971,8 +1982,8 @@ struct InvLaunch {
             if (fast) {
                 const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
-                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true>), grid, block, 0, st, jobs, f, Y, runlen, 0);
-                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1, true>), grid, block, 0, st, jobs, f, Y, runlen, 0);
+                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true>), grid, block, 0, st, jr, f, Y, runlen, 0);
+                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1, true>), grid, block, 0, st, jr, f, Y, runlen, 0);
                 return hipGetLastError();
             }
             // many outputs: the walker per output pair (see FwdLaunch)
@@ -1983,18 +1994,18 @@ struct InvLaunch {
                 const int runs = (max_blocks + runlen - 1) / runlen;
                 const int wxl = runs >= 8 ? 1 : 0;
                 const dim3 grid = wxl ? dim3(8 * pairs, (runs + 7) / 8, njobs) : dim3(runs, pairs, njobs);
-                hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true, true>), grid, dim3(NT), 0, st, jobs, f, Y, runlen, wxl);
+                hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true, true>), grid, dim3(NT), 0, st, jr, f, Y, runlen, wxl);
                 return hipGetLastError();
             }
         }
         const int xl = max_blocks >= 8 ? 1 : 0;
         if (tn.fft_form != 1 && pairs_ok && f.cout >= 4 && f.cout % 2 == 0) {
             const dim3 grid = xl ? dim3(8 * (f.cout / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cout / 2, njobs);
-            hipLaunchKernelGGL(inverse_chpair_kernel<L>, grid, dim3(NT), 0, st, jobs, f, Y, xl);
+            hipLaunchKernelGGL(inverse_chpair_kernel<L>, grid, dim3(NT), 0, st, jr, f, Y, xl);
             return hipGetLastError();
         }
         const dim3 grid = xl ? dim3(8 * f.cout, (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cout, njobs);
-        hipLaunchKernelGGL(inverse_kernel<L>, grid, dim3(NT), 0, st, jobs, f, Y, xl);
+        hipLaunchKernelGGL(inverse_kernel<L>, grid, dim3(NT), 0, st, jr, f, Y, xl);
         return hipGetLastError();
     }
 };
@@ -2166,14 +2177,15 @@ bool choose_walk(const FilterDev& f, int njobs, int max_blocks, int np, WalkShap
     return out->kr != 0;
 }
 template <int KR, int D, int LPB, int NP = 1>
-void launch_walk(const StreamJob* jobs, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, hipStream_t st) {
+void launch_walk(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, hipStream_t st) {
     dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
-    hipLaunchKernelGGL((mac_walk_kernel<KR, D, true, 6, LPB, NP>), grid, block, 0, st, jobs, f, Y, w.tiles, w.tile_len);
+    hipLaunchKernelGGL((mac_walk_kernel<KR, D, true, 6, LPB, NP>), grid, block, 0, st, jr, f, Y, w.tiles, w.tile_len);
 }
 }  // namespace
 
 hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, float2* Y, int time_tile,
                       const MacShape& shape, const Tuning& tn, hipStream_t st) {
+    const JobRef jr = make_job_ref(jobs, tn);
     const int P2 = f.P / 2;
     int form = tn.mac_form;
     WalkShape ws{};
@@ -2203,26 +2215,26 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
         // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
         // waves start together and read 2 KB of a row between them: DRAM locality)
         if (ws.np == 2 && ws.lpb == 2) {
-            if (ws.kr == 17) launch_walk<17, 15, 2, 2>(jobs, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 2, 2>(jobs, njobs, f, Y, ws, st);
+            if (ws.kr == 17) launch_walk<17, 15, 2, 2>(jr, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 2, 2>(jr, njobs, f, Y, ws, st);
         } else if (ws.np == 2) {
-            if (ws.kr == 17) launch_walk<17, 15, 4, 2>(jobs, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 4, 2>(jobs, njobs, f, Y, ws, st);
+            if (ws.kr == 17) launch_walk<17, 15, 4, 2>(jr, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 4, 2>(jr, njobs, f, Y, ws, st);
         } else if (ws.np == 4) {
-            if (ws.kr == 9) launch_walk<9, 15, 4, 4>(jobs, njobs, f, Y, ws, st);
-            else if (ws.kr == 17) launch_walk<17, 15, 4, 4>(jobs, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 4, 4>(jobs, njobs, f, Y, ws, st);
+            if (ws.kr == 9) launch_walk<9, 15, 4, 4>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 17) launch_walk<17, 15, 4, 4>(jr, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 4, 4>(jr, njobs, f, Y, ws, st);
         } else if (ws.lpb == 1) {
-            if (ws.kr == 9) launch_walk<9, 7, 1>(jobs, njobs, f, Y, ws, st);
-            else if (ws.kr == 17) launch_walk<17, 7, 1>(jobs, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 1>(jobs, njobs, f, Y, ws, st);
+            if (ws.kr == 9) launch_walk<9, 7, 1>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 17) launch_walk<17, 7, 1>(jr, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 1>(jr, njobs, f, Y, ws, st);
         } else if (ws.lpb == 2) {
-            if (ws.kr == 17) launch_walk<17, 15, 2>(jobs, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 2>(jobs, njobs, f, Y, ws, st);
+            if (ws.kr == 17) launch_walk<17, 15, 2>(jr, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 2>(jr, njobs, f, Y, ws, st);
         } else {
-            if (ws.kr == 9) launch_walk<9, 15, 4>(jobs, njobs, f, Y, ws, st);
-            else if (ws.kr == 17) launch_walk<17, 15, 4>(jobs, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 4>(jobs, njobs, f, Y, ws, st);
+            if (ws.kr == 9) launch_walk<9, 15, 4>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 17) launch_walk<17, 15, 4>(jr, njobs, f, Y, ws, st);
+            else launch_walk<33, 7, 4>(jr, njobs, f, Y, ws, st);
         }
         return hipGetLastError();
     }
@@ -2233,16 +2245,15 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
             const int nt = pv < 256 ? pv : 256;
             const int tiles = (max_blocks + form - 1) / form;
             dim3 grid(pv / nt, f.cout * tiles, njobs), block(nt);
-            if (form == 16) hipLaunchKernelGGL((mac_slide_kernel<16, 1, 4>), grid, block, 0, st, jobs, f, Y, tiles);
-            else if (form == 8) hipLaunchKernelGGL((mac_slide_kernel<8, 2, 2>), grid, block, 0, st, jobs, f, Y, tiles);
-            else hipLaunchKernelGGL((mac_slide_kernel<4, 2, 2>), grid, block, 0, st, jobs, f, Y, tiles);
+            if (form == 16) hipLaunchKernelGGL((mac_slide_kernel<16, 1, 4>), grid, block, 0, st, jr, f, Y, tiles);
+            else if (form == 8) hipLaunchKernelGGL((mac_slide_kernel<8, 2, 2>), grid, block, 0, st, jr, f, Y, tiles);
+            else hipLaunchKernelGGL((mac_slide_kernel<4, 2, 2>), grid, block, 0, st, jr, f, Y, tiles);
             return hipGetLastError();
         }
     }
     if (form == 1 && max_blocks == 1 && njobs <= 8 && P2 >= 64 && tn.mac_form == 0) {
         dim3 grid(P2 / 64, f.cout, njobs), block(64);
-        if (tn.one_job) hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, (const StreamJob*)nullptr, *tn.one_job, f, Y);
-        else hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, jobs, StreamJob{}, f, Y);
+        hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, jr, f, Y);
         return hipGetLastError();
     }
     const int nt = P2 < 256 ? P2 : 256;
@@ -2251,11 +2262,11 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     const int tiles = (max_blocks + tt - 1) / tt;
     dim3 grid(P2 / nt, f.cout * tiles, njobs), block(nt);
     switch (tt) {
-        case 1: hipLaunchKernelGGL(mac_kernel<1>, grid, block, 0, st, jobs, f, Y, tiles); break;
-        case 2: hipLaunchKernelGGL(mac_kernel<2>, grid, block, 0, st, jobs, f, Y, tiles); break;
-        case 4: hipLaunchKernelGGL(mac_kernel<4>, grid, block, 0, st, jobs, f, Y, tiles); break;
-        case 8: hipLaunchKernelGGL(mac_kernel<8>, grid, block, 0, st, jobs, f, Y, tiles); break;
-        default: hipLaunchKernelGGL(mac_kernel<16>, grid, block, 0, st, jobs, f, Y, tiles); break;
+        case 1: hipLaunchKernelGGL(mac_kernel<1>, grid, block, 0, st, jr, f, Y, tiles); break;
+        case 2: hipLaunchKernelGGL(mac_kernel<2>, grid, block, 0, st, jr, f, Y, tiles); break;
+        case 4: hipLaunchKernelGGL(mac_kernel<4>, grid, block, 0, st, jr, f, Y, tiles); break;
+        case 8: hipLaunchKernelGGL(mac_kernel<8>, grid, block, 0, st, jr, f, Y, tiles); break;
+        default: hipLaunchKernelGGL(mac_kernel<16>, grid, block, 0, st, jr, f, Y, tiles); break;
     }
     return hipGetLastError();
 }
