@@ -37,6 +37,10 @@ const int kMaxRunAhead = 1024;
 // 64 blocks = 12 s of 44.1 kHz audio per chunk: 8 MB of page-locked ring and 12.6 MB of delay line per open stereo file
 // at 256 k taps.  Measured with 64 file threads on one MI355X: depth 8: 5.5, 32: 8.0, 64: 9.0, 128: 9.2 Gsamples/s.
 const int kDefaultRunAhead = 64;
+// What one processor may pin for its two chunks: streams of many channels run ahead by fewer blocks (a block of a
+// 64-channel stream is 2 MB; 64 of them twice over would pin 256 MB per open file).  Stereo and 8-channel streams at
+// the default depth stay below it (8 and 32 MB).
+const size_t kRingBudgetBytes = static_cast<size_t>(64) << 20;
 }  // namespace
 
 void SoundProcessor::SetDevicePeaks(bool on) { g_device_peaks.store(on); }
@@ -86,7 +90,13 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     fe_stream* stream = NULL;
     // The stream's delay line is sized for the longest call this processor will make: its run-ahead depth
     // (one block per call is the reference's contract and what depth 1 gives).
-    const int run_depth = RunAhead();
+    int run_depth = RunAhead();
+    {
+        const size_t in = static_cast<size_t>(zita.fragm) * zita.ninp, out = static_cast<size_t>(zita.fragm) * zita.nout;
+        const size_t block_bytes = (zita.ninp == zita.nout ? in : in + out) * sizeof(float);     // (ChunkFloats, below)
+        const size_t fit = block_bytes ? kRingBudgetBytes / (2 * block_bytes) : static_cast<size_t>(run_depth);
+        if (fit < static_cast<size_t>(run_depth)) run_depth = static_cast<int>(std::max<size_t>(fit, 1));
+    }
     const int rc = fe_stream_open(filter, run_depth, &stream);
     fe_filter_release(filter);           // the stream holds its own reference
     if (rc != 0) {

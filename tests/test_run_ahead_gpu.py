@@ -194,6 +194,30 @@ def test_run_ahead_with_unequal_channel_counts_and_small_blocks(oracle, tmp_path
     assert oracle.rms(y - exp) <= 1e-6
 
 
+def test_many_channels_run_ahead_by_fewer_blocks(oracle, tmp_path, depth):
+    """A processor pins at most 64 MB for its two chunks: a block of a 32-channel stream at P = 8192 is 1 MB, so the
+    depth asked for (64) becomes 32; the block machine's results do not know (dirac paths: closed form)."""
+    conf = os.path.join(str(tmp_path), "filter-44100.conf")
+    with open(conf, "w") as f:
+        f.write("/convolver/new 32 32 256 20000\n")
+        for c in range(32):
+            f.write("/impulse/dirac %d %d %.3f %d\n" % (c + 1, c + 1, 0.5 + 0.01 * c, 100 * c))
+    depth(64)
+    sp = H.SoundProcessor.create(conf, 44100, 32)
+    assert (sp.ninp, sp.nout, sp.fragm) == (32, 32, 8192)
+    assert sp.run_ahead() == 32
+    x = seeded_input(5, 37 * 8192 + 1234, 32)
+    y = sp.run(x)
+    exp = np.zeros_like(x, dtype=np.float64)
+    for c in range(32):
+        d = 100 * c
+        exp[d:, c] = (0.5 + 0.01 * c) * x[:len(x) - d, c]
+    assert oracle.rms(y - exp) <= 1e-6
+    depth(64)
+    stereo = H.SoundProcessor.create(os.path.join(make_echo_filter_dir(tmp_path), "filter-44100.conf"), 44100, 2)
+    assert stereo.run_ahead() == 64
+
+
 def test_lanes_on_and_off_give_the_same_bits(oracle, tmp_path, depth):
     """FE_TUNE_LANES = 1 puts every submitted batch on the engine's own stream: the arithmetic does not know."""
     d, hs = make_pass_filter_dir(tmp_path, "lowpass"), None
