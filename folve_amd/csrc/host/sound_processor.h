@@ -67,9 +67,11 @@ public:
     // Same, on a given engine (used by ProcessorPool's sharder).
     static SoundProcessor* CreateOn(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
     // Blocks a processor may read ahead of its reader (1 = off: one block per engine call, the reference's
-    // pattern).  Applies to processors created afterwards.  Default 64, or FOLVE_AMD_RUN_AHEAD.
+    // pattern; 0 = automatic).  Applies to processors created afterwards.  Default: automatic (or FOLVE_AMD_RUN_AHEAD) —
+    // 64 blocks of 8192 frames, the same number of frames for shorter blocks (up to 1024 blocks), fewer blocks where
+    // the page-locked ring would pass 64 MB (many channels); run_ahead() tells what a processor got.
     static void SetRunAhead(int blocks);
-    static int RunAhead();
+    static int RunAhead();              // the configured depth in blocks (64 when automatic)
     // Where a run-ahead block's maxima come from: the GPU (K3 reduces every block; default) or a scan of the block on
     // the caller's thread when it is handed out (what the reference does, sound-processor.cc:116-125).
     static void SetDevicePeaks(bool on);

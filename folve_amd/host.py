@@ -227,11 +227,12 @@ def batching_stats():
     return dict(zip(("requests", "blocks", "batches", "largest", "overlapped"), [x.value for x in v]))
 
 
-DEFAULT_RUN_AHEAD = 64
+DEFAULT_RUN_AHEAD = 64     # blocks of 8192 frames; the automatic setting gives shorter blocks as many frames (up to 1024 blocks)
+AUTO_RUN_AHEAD = 0         # set_run_ahead(AUTO_RUN_AHEAD): back to the automatic depth
 
 
 def set_run_ahead(blocks):
-    """Run-ahead depth (blocks) of SoundProcessors created from now on; 1 = off (folve::SoundProcessor::SetRunAhead)."""
+    """Run-ahead depth (blocks) of SoundProcessors created from now on; 1 = off, 0 = automatic (folve::SoundProcessor::SetRunAhead)."""
     _L().fh_run_ahead_set(int(blocks))
 
 

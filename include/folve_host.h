@@ -47,7 +47,8 @@ typedef int (*fh_read_fn)(void *user, float *dst, int frames);
 typedef int (*fh_write_fn)(void *user, const float *src, int frames);
 int fh_processor_fill_buffer_from(fh_processor *p, fh_read_fn read, void *user);
 void fh_processor_write_processed_to(fh_processor *p, fh_write_fn write, void *user, int sample_count);
-/* Run-ahead depth in blocks for processors created from now on (1 = off; default 64 or FOLVE_AMD_RUN_AHEAD);
+/* Run-ahead depth in blocks for processors created from now on (1 = off; 0 = automatic, the default unless FOLVE_AMD_RUN_AHEAD is set:
+ * 64 blocks of 8192 frames, as many frames for shorter blocks, fewer blocks for streams of many channels);
  * fh_processor_run_ahead: the depth a given processor was created with. */
 void fh_device_peaks_set(int on);       /* run-ahead blocks' maxima from the GPU (1, default) or scanned on the caller's thread (0) */
 void fh_run_ahead_set(int blocks);

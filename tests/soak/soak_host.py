@@ -67,5 +67,5 @@ for r in range(rounds):
         if not (len(y) == len(x) and e <= 1e-5):
             bad += 1
             print("round", r, "depth", depth, "file", i, "frames", len(x), "FAILED rms", e)
-H.set_run_ahead(H.DEFAULT_RUN_AHEAD)
+H.set_run_ahead(H.AUTO_RUN_AHEAD)
 print("soak_host done: %d rounds x %d threads, %d files, failures: %d, %.1f s; combiner %s" % (rounds, nthreads, nfiles, bad, time.time() - t0, H.batching_stats()))

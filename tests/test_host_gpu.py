@@ -191,7 +191,7 @@ def test_combiner_coalesces_one_block_calls_and_is_bit_identical(oracle, tmp_pat
     try:
         _combiner_one_block_calls(oracle, tmp_path)
     finally:
-        H.set_run_ahead(H.DEFAULT_RUN_AHEAD)
+        H.set_run_ahead(H.AUTO_RUN_AHEAD)
 
 
 def _combiner_one_block_calls(oracle, tmp_path):

@@ -26,7 +26,7 @@ def depth():
     def set_depth(n):
         H.set_run_ahead(n)
     yield set_depth
-    H.set_run_ahead(H.DEFAULT_RUN_AHEAD)
+    H.set_run_ahead(H.AUTO_RUN_AHEAD)
 
 
 def _call_log(sp, x, split=False):
@@ -216,6 +216,30 @@ def test_many_channels_run_ahead_by_fewer_blocks(oracle, tmp_path, depth):
     depth(64)
     stereo = H.SoundProcessor.create(os.path.join(make_echo_filter_dir(tmp_path), "filter-44100.conf"), 44100, 2)
     assert stereo.run_ahead() == 64
+
+
+def test_automatic_depth_follows_the_block_size(oracle, tmp_path, depth):
+    """Automatic run-ahead: 64 blocks of 8192 frames, the same number of frames for shorter blocks (at most 1024 blocks);
+    an explicit depth is taken as given.  The results do not depend on it (dirac paths: closed form)."""
+    depth(H.AUTO_RUN_AHEAD)
+    conf = os.path.join(str(tmp_path), "filter-44100.conf")
+    got = {}
+    for size, fragm, want in ((1500, 2048, 256), (100, 128, 1024), (20000, 8192, 64)):
+        with open(conf, "w") as f:
+            f.write("/convolver/new 2 2 256 %d\n/impulse/dirac 1 1 0.5 0\n/impulse/dirac 2 2 0.25 %d\n" % (size, size - 1))
+        os.utime(conf, (1000 + size, 1000 + size))                          # (another configuration for the filter cache)
+        sp = H.SoundProcessor.create(conf, 44100, 2)
+        assert sp.fragm == fragm and sp.run_ahead() == want, (size, sp.fragm, sp.run_ahead())
+        x = seeded_input(size, 300 * fragm + 17, 2)
+        y = sp.run(x)
+        exp = np.zeros_like(x, dtype=np.float64)
+        exp[:, 0] = 0.5 * x[:, 0]
+        exp[size - 1:, 1] = 0.25 * x[:len(x) - (size - 1), 1]
+        assert oracle.rms(y - exp) <= 1e-6, size
+        got[size] = y
+    depth(8)
+    sp = H.SoundProcessor.create(conf, 44100, 2)
+    assert sp.run_ahead() == 8
 
 
 def test_lanes_on_and_off_give_the_same_bits(oracle, tmp_path, depth):
