@@ -47,6 +47,7 @@ ENGINE_SYMBOLS = [
     ("fe_engine_destroy", None, [_vp]),
     ("fe_engine_synchronize", _i, [_vp]),
     ("fe_engine_device", _i, [_vp]),
+    ("fe_engine_probe", _i, [_vp]),
     ("fe_last_error", C.c_char_p, []),
     ("fe_fragm_for_size", _i, [C.c_uint]),
     ("fe_filter_create", _i, [_vp, _i, _i, _i, _f, _pvp]),

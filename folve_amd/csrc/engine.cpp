@@ -1595,6 +1595,22 @@ int fe_debug_xlane(fe_engine* e, float* out512) {
     return FE_OK;
 }
 
+// A small round trip through the engine: a kernel on its stream and its result back on the host.  What the host's
+// GPU sharder asks a GPU that failed before it sends files there again (host/device_router.cpp).
+int fe_engine_probe(fe_engine* e) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->fail_round_in < 0) return fail(FE_ERR_DEVICE, "injected device failure (test hook)");
+    HIP_TRY(hipSetDevice(e->device));
+    DevTmp buf;
+    HIP_TRY(hipMalloc(&buf.p, 512 * sizeof(float)));
+    float out[512];
+    HIP_TRY(fk::launch_xlane_selftest(static_cast<float*>(buf.p), e->stream));
+    HIP_TRY(hipMemcpyAsync(out, buf.p, sizeof(out), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FE_OK;
+}
+
 // ---- measurement hooks ------------------------------------------------------
 int fe_engine_set_profiling(fe_engine* e, int on) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");

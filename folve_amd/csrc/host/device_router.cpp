@@ -3,6 +3,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
 
 namespace folve {
 
@@ -27,36 +32,148 @@ DeviceRouter* DeviceRouter::Default() {
     return router;
 }
 
+namespace {
+double Now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return static_cast<double>(ts.tv_sec) + 1e-9 * static_cast<double>(ts.tv_nsec);
+}
+}  // namespace
+
 DeviceRouter::DeviceRouter(const std::vector<int>& devices) {
-    for (int d : devices) slots_.push_back(Slot{d, NULL, 0});
+    for (int d : devices) slots_.push_back(std::unique_ptr<Slot>(new Slot(d)));
+    if (const char* env = getenv("FOLVE_AMD_FENCE_AFTER")) if (atoi(env) > 0) fence_after_ = atoi(env);
+    if (const char* env = getenv("FOLVE_AMD_REPROBE_SECONDS")) if (atof(env) >= 0) reprobe_s_ = atof(env);
 }
 
 DeviceRouter::~DeviceRouter() {
+    {
+        std::unique_lock<std::mutex> lk(mu_);        // a probe thread still out there touches the slots
+        probed_.wait(lk, [this] { return probes_in_flight_ == 0; });
+    }
     for (auto& kv : filters_) fe_filter_release(kv.second.filter);
-    for (Slot& s : slots_)
-        if (s.engine) fe_engine_destroy(s.engine);
+    for (auto& s : slots_)
+        if (s->engine) fe_engine_destroy(s->engine);
 }
 
-fe_engine* DeviceRouter::PickEngine() {
-    std::lock_guard<std::mutex> lk(mu_);
-    Slot* best = NULL;
-    for (Slot& s : slots_)
-        if (!best || s.live < best->live) best = &s;
-    if (!best) return NULL;
-    if (!best->engine && fe_engine_create(best->device, NULL, &best->engine) != 0) {
-        Logf("GPU %d unusable: %s", best->device, fe_last_error());
-        return NULL;
+DeviceRouter::Slot* DeviceRouter::SlotOfLocked(fe_engine* e) const {
+    if (!e) return NULL;
+    for (auto& s : slots_) if (s->engine == e) return s.get();
+    return NULL;
+}
+
+// One look at a slot that is not healthy: (re)create its engine if it never came up, then a small round trip through
+// it.  The look runs on a thread of its own and the opener waits for it for a bounded time only — a GPU that hangs
+// must not hang the file that is being opened; `probing` keeps everybody off the slot until the look has returned,
+// however late.  The lock is dropped while waiting.
+bool DeviceRouter::ProbeSlot(Slot* s, std::unique_lock<std::mutex>* lk) {
+    s->probing = true;
+    probes_in_flight_++;
+    const int slot_index = static_cast<int>(std::find_if(slots_.begin(), slots_.end(),
+                                                         [&](const std::unique_ptr<Slot>& p) { return p.get() == s; }) - slots_.begin());
+    std::thread([this, s, slot_index] {
+        fe_engine* e;
+        { std::lock_guard<std::mutex> g(mu_); e = s->engine; }
+        bool ok = true;
+        fe_engine* created = NULL;
+        if (!e) {
+            ok = fe_engine_create(s->device, NULL, &created) == 0;
+            e = created;
+        }
+        if (ok) ok = fe_engine_probe(e) == 0;
+        const std::string why = ok ? std::string() : std::string(fe_last_error());
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (created) s->engine = created;        // nobody else creates it while `probing`
+            s->looked_at = Now();
+            if (ok) {
+                if (s->state.load() != kHealthy) Logf("GPU %d (slot %d) answers again: back in service", s->device, slot_index);
+                s->state.store(kHealthy);
+                s->fail_streak = 0;
+            } else {
+                s->failures++;
+                s->fail_streak++;
+                s->state.store(kFenced);             // it was asked directly and said no
+                Logf("GPU %d (slot %d) still unusable: %s", s->device, slot_index, why.c_str());
+            }
+            s->probing = false;
+            probes_in_flight_--;
+        }
+        probed_.notify_all();
+    }).detach();
+    // (wait_until on the system clock: pthread_cond_timedwait, which ThreadSanitizer knows, unlike the clockwait of wait_for)
+    probed_.wait_until(*lk, std::chrono::system_clock::now() + std::chrono::microseconds(static_cast<long long>(probe_wait_s_ * 1e6)),
+                       [s] { return !s->probing; });
+    if (s->probing) {
+        Logf("GPU %d (slot %d) does not answer its probe: left out until it does", s->device, slot_index);
+        return false;
     }
-    best->live++;          // reserved under the same lock as the choice: concurrent opens alternate exactly
-    return best->engine;
+    return s->state.load() == kHealthy;
+}
+
+// The least-loaded healthy slot; suspect ones only when no healthy one is left, fenced ones never — but any slot that is
+// not healthy and has not been looked at for the re-probe interval is probed first, and when nothing else is left the
+// least recently probed ones are probed at once (a daemon whose only GPU hiccupped must find it again).
+fe_engine* DeviceRouter::PickEngine(const std::vector<fe_engine*>* tried) {
+    std::unique_lock<std::mutex> lk(mu_);
+    auto was_tried = [&](const Slot* s) {
+        if (!tried || !s->engine) return false;
+        for (fe_engine* t : *tried) if (t == s->engine) return true;
+        return false;
+    };
+    std::set<const Slot*> gave_up;                   // slots this very call has probed without success
+    for (;;) {
+        const double now = Now();
+        Slot* best = NULL;
+        Slot* due = NULL;                            // a sick slot whose re-probe is due
+        Slot* sick = NULL;                           // the sick slot looked at longest ago (last resort)
+        for (auto& sp : slots_) {
+            Slot* s = sp.get();
+            if (was_tried(s) || gave_up.count(s) || s->probing) continue;
+            const int st = s->state.load();
+            if (st != kHealthy) {
+                if (now - s->looked_at >= reprobe_s_ && (!due || s->looked_at < due->looked_at)) due = s;
+                if (!sick || s->looked_at < sick->looked_at) sick = s;
+            }
+            if (st == kFenced) continue;
+            if (!best || st < best->state.load() || (st == best->state.load() && s->live < best->live)) best = s;
+        }
+        if (due) {
+            if (!ProbeSlot(due, &lk)) gave_up.insert(due);
+            continue;                                // choose again with what the probe found
+        }
+        if (!best) {
+            if (!sick) return NULL;
+            if (!ProbeSlot(sick, &lk)) gave_up.insert(sick);
+            continue;
+        }
+        if (!best->engine) {
+            // first use of this GPU.  Creating an engine takes a while (context, tables): still under the lock, as in
+            // round 3 — it happens once per GPU.
+            if (fe_engine_create(best->device, NULL, &best->engine) != 0) {
+                Logf("GPU %d unusable: %s", best->device, fe_last_error());
+                best->engine = NULL;
+                best->failures++;
+                best->fail_streak = fence_after_;
+                best->state.store(kFenced);
+                best->looked_at = Now();
+                gave_up.insert(best);
+                continue;                            // the next GPU
+            }
+        }
+        best->live++;      // reserved under the same lock as the choice: concurrent opens alternate exactly
+        return best->engine;
+    }
 }
 
 fe_engine* DeviceRouter::EngineForDevice(int device) {
     std::lock_guard<std::mutex> lk(mu_);
-    for (Slot& s : slots_) {
+    for (auto& sp : slots_) {
+        Slot& s = *sp;
         if (s.device != device) continue;
         if (!s.engine && fe_engine_create(s.device, NULL, &s.engine) != 0) {
             Logf("GPU %d unusable: %s", s.device, fe_last_error());
+            s.engine = NULL;
             return NULL;
         }
         return s.engine;
@@ -66,17 +183,81 @@ fe_engine* DeviceRouter::EngineForDevice(int device) {
 
 fe_engine* DeviceRouter::EngineIfCreated(int slot) {
     std::lock_guard<std::mutex> lk(mu_);
-    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)].engine : NULL;
+    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)]->engine : NULL;
 }
 
 void DeviceRouter::StreamOpened(fe_engine* e) {
     std::lock_guard<std::mutex> lk(mu_);
-    for (Slot& s : slots_) if (s.engine == e) s.live++;
+    if (Slot* s = SlotOfLocked(e)) s->live++;
 }
 
 void DeviceRouter::StreamClosed(fe_engine* e) {
     std::lock_guard<std::mutex> lk(mu_);
-    for (Slot& s : slots_) if (s.engine == e && s.live > 0) s.live--;
+    Slot* s = SlotOfLocked(e);
+    if (s && s->live > 0) s->live--;
+}
+
+void DeviceRouter::ReportFailure(fe_engine* e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    Slot* s = SlotOfLocked(e);
+    if (!s) return;
+    s->failures++;
+    s->fail_streak++;
+    s->looked_at = Now();
+    const int was = s->state.load();
+    const int now = s->fail_streak >= fence_after_ ? kFenced : kSuspect;
+    if (now > was) {
+        s->state.store(now);
+        if (now == kFenced)
+            Logf("GPU %d (slot %d) fenced after %d consecutive failures: new files go to the other GPUs", s->device,
+                 static_cast<int>(s - slots_[0].get()), s->fail_streak);
+    }
+}
+
+void DeviceRouter::ReportSuccess(fe_engine* e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    Slot* s = SlotOfLocked(e);
+    if (!s || (s->state.load() == kHealthy && s->fail_streak == 0)) return;
+    s->fail_streak = 0;
+    s->state.store(kHealthy);
+}
+
+const std::atomic<int>* DeviceRouter::HealthFlag(fe_engine* e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    Slot* s = SlotOfLocked(e);
+    return s ? &s->state : NULL;
+}
+
+bool DeviceRouter::EngineUsable(fe_engine* e) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    const Slot* s = SlotOfLocked(e);
+    return !s || s->state.load() != kFenced;
+}
+
+DeviceRouter::SlotState DeviceRouter::slot_state(int slot) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    return (slot >= 0 && slot < static_cast<int>(slots_.size()))
+               ? static_cast<SlotState>(slots_[static_cast<size_t>(slot)]->state.load()) : kFenced;
+}
+
+long long DeviceRouter::slot_failures(int slot) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)]->failures : 0;
+}
+
+void DeviceRouter::SetFenceAfter(int n) {
+    std::lock_guard<std::mutex> lk(mu_);
+    fence_after_ = n > 0 ? n : 3;
+}
+
+void DeviceRouter::SetProbeWaitSeconds(double seconds) {
+    std::lock_guard<std::mutex> lk(mu_);
+    probe_wait_s_ = seconds > 0 ? seconds : 2.0;
+}
+
+void DeviceRouter::SetReprobeSeconds(double seconds) {
+    std::lock_guard<std::mutex> lk(mu_);
+    reprobe_s_ = seconds >= 0 ? seconds : 10.0;
 }
 
 int DeviceRouter::cached_filters() const {
@@ -86,7 +267,7 @@ int DeviceRouter::cached_filters() const {
 
 int DeviceRouter::live_streams(int slot) const {
     std::lock_guard<std::mutex> lk(mu_);
-    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)].live : 0;
+    return (slot >= 0 && slot < static_cast<int>(slots_.size())) ? slots_[static_cast<size_t>(slot)]->live : 0;
 }
 
 // A cached filter that only the cache still holds (no stream uses it) and whose configuration file has changed or
@@ -114,13 +295,18 @@ void DeviceRouter::SweepLocked() {
 }
 
 fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_file, time_t mtime, int samplerate,
-                                   int channels, ZitaConfig* out_cfg, FileStamps* impulse_files) {
+                                   int channels, ZitaConfig* out_cfg, FileStamps* impulse_files, bool* engine_fault) {
     const std::pair<std::string, fe_engine*> key(config_file, engine);
     {
         // The reference serialises Create() as a whole (sound-processor.cc:43); here only the bookkeeping is
         // serialised, and two threads never build the same (configuration, GPU) at once.
         std::unique_lock<std::mutex> lk(mu_);
-        SweepLocked();
+        // (the sweep stats every cached configuration and its impulse files under the lock: at most once a second,
+        // not on every open — the reference looks at one mtime per open, sound-processor.cc:129-133)
+        if (const double now = Now(); now - last_sweep_ >= 1.0) {
+            last_sweep_ = now;
+            SweepLocked();
+        }
         for (;;) {
             auto it = filters_.find(key);
             if (it != filters_.end()) {
@@ -167,6 +353,7 @@ fe_filter* DeviceRouter::GetFilter(fe_engine* engine, const std::string& config_
     if (fe_filter_commit(zita.filter) != 0) {
         Logf("Cannot transform filter %s on GPU %d: %s", config_file.c_str(), fe_engine_device(engine), fe_last_error());
         fe_filter_release(zita.filter);
+        if (engine_fault) *engine_fault = true;          // it parsed: the transform is what failed
         return NULL;
     }
     zita.config_file = NULL;

@@ -100,8 +100,12 @@ fh_processor* fh_processor_create(const char* config_file, int samplerate, int c
 }
 void fh_processor_destroy(fh_processor* p) { delete SP(p); }
 
+// The span form keeps the reference's contract to the letter — it takes exactly the frames it returns — so the source
+// it shows the processor ends where the current block ends: a processor with run-ahead then never reads beyond what
+// it hands back (it sees a file that always ends at the block boundary, and falls back to one block per engine call).
+// Hosts that want run-ahead use fh_processor_fill_buffer2 or the callback form.
 int fh_processor_fill_buffer(fh_processor* p, const float* src, int frames_available) {
-    SpanSource s(src, frames_available, SP(p)->input_channels());
+    SpanSource s(src, std::min(frames_available, SP(p)->frames_wanted()), SP(p)->input_channels());
     return SP(p)->FillBuffer(&s);
 }
 int fh_processor_fill_buffer2(fh_processor* p, const float* src, int frames_available, int* consumed) {
@@ -197,5 +201,13 @@ int fh_pin_thread_near_device(int device) { return folve::PinThreadNearDevice(de
 int fh_router_device_count(void) { return folve::DeviceRouter::Default()->device_count(); }
 int fh_router_live_streams(int slot) { return folve::DeviceRouter::Default()->live_streams(slot); }
 int fh_router_cached_filters(void) { return folve::DeviceRouter::Default()->cached_filters(); }
+int fh_router_slot_state(int slot) { return static_cast<int>(folve::DeviceRouter::Default()->slot_state(slot)); }
+long long fh_router_slot_failures(int slot) { return folve::DeviceRouter::Default()->slot_failures(slot); }
+fe_engine* fh_router_slot_engine(int slot) { return folve::DeviceRouter::Default()->EngineIfCreated(slot); }
+void fh_router_health_policy(int fence_after, double reprobe_seconds) {
+    if (fence_after > 0) folve::DeviceRouter::Default()->SetFenceAfter(fence_after);
+    if (reprobe_seconds >= 0) folve::DeviceRouter::Default()->SetReprobeSeconds(reprobe_seconds);
+}
+void fh_router_report_failure(fe_engine* e) { folve::DeviceRouter::Default()->ReportFailure(e); }
 
 }  // extern "C"

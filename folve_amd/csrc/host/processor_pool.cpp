@@ -10,6 +10,7 @@
 
 #include <vector>
 
+#include "device_router.h"
 #include "sound_processor.h"
 
 namespace folve {
@@ -64,9 +65,19 @@ SoundProcessor* ProcessorPool::GetOrCreate(const std::string& base_dir, int samp
     }
     SoundProcessor* result;
     while ((result = CheckOutOfPool(config_path)) != NULL) {
-        if (result->ConfigStillUpToDate()) break;
-        Logf("Processor %p: outdated; config file changed %s", static_cast<void*>(result), config_path.c_str());
-        delete result;
+        if (!result->ConfigStillUpToDate()) {
+            Logf("Processor %p: outdated; config file changed %s", static_cast<void*>(result), config_path.c_str());
+            delete result;
+            continue;
+        }
+        // the same discard-and-look-again for a processor whose GPU has been fenced since it was pooled: it would
+        // only hand its next file silence
+        if (!DeviceRouter::Default()->EngineUsable(result->engine())) {
+            Logf("Processor %p: discarded; its GPU %d is fenced", static_cast<void*>(result), result->device());
+            delete result;
+            continue;
+        }
+        break;
     }
     if (result != NULL) return result;
 
@@ -84,7 +95,7 @@ void ProcessorPool::Return(SoundProcessor* processor) {
         delete processor;     // outdated: not returning it to the pool
         return;
     }
-    if (!processor->ok()) {
+    if (!processor->ok() || !DeviceRouter::Default()->EngineUsable(processor->engine())) {
         // The GPU failed under this processor: its convolver state is undefined (folve_engine.h),
         // so it must not be handed to the next file.
         Logf("Processor %p: discarded after an engine failure", static_cast<void*>(processor));

@@ -74,26 +74,38 @@ static int RunAheadForBlock(int fragm) {
 }
 
 SoundProcessor* SoundProcessor::Create(const std::string& config_file, int samplerate, int channels) {
-    fe_engine* engine = DeviceRouter::Default()->PickEngine();
-    if (!engine) {
-        Logf("No usable GPU: cannot create a processor for %s (there is no CPU fallback)", config_file.c_str());
-        return NULL;
+    // The GPU comes from the router; if that GPU fails under the open (its engine cannot transform the filter or hold
+    // the stream), the open moves on to the next one: only a broken configuration, or no GPU left, fails it.
+    DeviceRouter* router = DeviceRouter::Default();
+    std::vector<fe_engine*> tried;
+    for (;;) {
+        fe_engine* engine = router->PickEngine(&tried);
+        if (!engine) {
+            Logf("No usable GPU: cannot create a processor for %s (there is no CPU fallback)", config_file.c_str());
+            return NULL;
+        }
+        bool engine_fault = false;
+        SoundProcessor* p = CreateOnReserved(engine, config_file, samplerate, channels, &engine_fault);
+        if (p) return p;
+        router->StreamClosed(engine);                           // give the reservation back
+        if (!engine_fault) return NULL;                         // the configuration's fault: the same on every GPU
+        router->ReportFailure(engine);
+        tried.push_back(engine);
     }
-    SoundProcessor* p = CreateOnReserved(engine, config_file, samplerate, channels);
-    if (!p) DeviceRouter::Default()->StreamClosed(engine);      // give the reservation back
-    return p;
 }
 
 SoundProcessor* SoundProcessor::CreateOn(fe_engine* engine, const std::string& config_file, int samplerate,
                                          int channels) {
-    SoundProcessor* p = CreateOnReserved(engine, config_file, samplerate, channels);
+    bool engine_fault = false;
+    SoundProcessor* p = CreateOnReserved(engine, config_file, samplerate, channels, &engine_fault);
     if (p) DeviceRouter::Default()->StreamOpened(engine);
+    else if (engine_fault) DeviceRouter::Default()->ReportFailure(engine);
     return p;
 }
 
 // The caller has already accounted the stream to `engine` in the router.
 SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate,
-                                                 int channels) {
+                                                 int channels, bool* engine_fault) {
     if (!engine) return NULL;
     ZitaConfig zita;
     memset(&zita, 0, sizeof(zita));
@@ -101,7 +113,7 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     // processor of that configuration shares the committed spectra.
     DeviceRouter::FileStamps impulse_files;
     fe_filter* filter = DeviceRouter::Default()->GetFilter(engine, config_file, GetModificationTime(config_file),
-                                                           samplerate, channels, &zita, &impulse_files);
+                                                           samplerate, channels, &zita, &impulse_files, engine_fault);
     if (!filter) return NULL;
     fe_stream* stream = NULL;
     // The stream's delay line is sized for the longest call this processor will make: its run-ahead depth
@@ -117,6 +129,7 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     fe_filter_release(filter);           // the stream holds its own reference
     if (rc != 0) {
         Logf("Cannot open a convolver stream for %s: %s", config_file.c_str(), fe_last_error());
+        if (engine_fault) *engine_fault = true;                 // (device memory, the device itself)
         return NULL;
     }
     zita.engine = engine;
@@ -160,7 +173,8 @@ SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg,
       arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth)),
       buffer_(AllocBlockBuffer(arena_floats_, &buffer_pinned_)),
       cur_(NULL), ahead_(NULL), ring_block_(NULL), tail_(NULL), tail_frames_(0), source_short_(false), depth_next_(1),
-      input_pos_(0), output_pos_(0), max_out_value_observed_(0.0), max_abs_value_observed_(0.0), ok_(true) {
+      input_pos_(0), output_pos_(0), max_out_value_observed_(0.0), max_abs_value_observed_(0.0), ok_(true),
+      slot_health_(DeviceRouter::Default()->HealthFlag(config.engine)) {
     if (buffer_pinned_ && fe_stream_bind_host_buffer(stream_, buffer_, arena_floats_ * sizeof(float)) != 0) {
         Logf("Processor %p: block buffer not bound (%s): blocks will be staged", static_cast<void*>(this), fe_last_error());
     }
@@ -190,6 +204,18 @@ SoundProcessor::~SoundProcessor() {
 }
 
 int SoundProcessor::device() const { return fe_engine_device(zita_config_.engine); }
+
+// What the GPU sharder hears of this processor's engine calls: every failure, and a success only while the slot is
+// not healthy (one relaxed load otherwise).
+void SoundProcessor::EngineCallFailed() {
+    ok_ = false;                         // ProcessorPool::Return will not pool this processor
+    DeviceRouter::Default()->ReportFailure(zita_config_.engine);
+}
+
+void SoundProcessor::EngineCallSucceeded() {
+    if (slot_health_ && slot_health_->load(std::memory_order_relaxed) != 0 && ok_)
+        DeviceRouter::Default()->ReportSuccess(zita_config_.engine);
+}
 
 // Ask the source for the next chunk (depth_next_ whole blocks).  Whole blocks stay in the chunk; frames beyond
 // the last whole block — the file's short last block — are moved to tail_.  A short read stops further
@@ -225,7 +251,9 @@ void SoundProcessor::SubmitChunk(Chunk* c) {
     if (rc != 0) {
         Logf("GPU convolution failed (%d): %s", rc, fe_last_error());
         memset(c->out, 0, sizeof(float) * frames * output_channels());
-        ok_ = false;
+        EngineCallFailed();
+    } else {
+        EngineCallSucceeded();
     }
 }
 
@@ -238,7 +266,9 @@ void SoundProcessor::SettleChunk(Chunk* c) {
     if (rc != 0) {
         Logf("GPU convolution failed (%d): %s", rc, error.c_str());
         memset(c->out, 0, sizeof(float) * static_cast<size_t>(c->blocks) * zita_config_.fragm * output_channels());
-        ok_ = false;                     // ProcessorPool::Return will not pool this processor
+        EngineCallFailed();
+    } else {
+        EngineCallSucceeded();
     }
 }
 
@@ -362,9 +392,10 @@ void SoundProcessor::Process() {
         if (rc != 0) {
             Logf("GPU convolution failed (%d): %s", rc, error.c_str());
             memset(buffer_, 0, sizeof(float) * n);
-            ok_ = false;                 // ProcessorPool::Return will not pool this processor
+            EngineCallFailed();
         } else {
             ScanPeaks(buffer_, n);
+            EngineCallSucceeded();
         }
     }
     output_pos_ = 0;

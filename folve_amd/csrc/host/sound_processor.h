@@ -31,6 +31,7 @@
 
 #include <time.h>
 
+#include <atomic>
 #include <string>
 #include <utility>
 #include <vector>
@@ -76,7 +77,8 @@ public:
     // the caller's thread when it is handed out (what the reference does, sound-processor.cc:116-125).
     static void SetDevicePeaks(bool on);
 private:
-    static SoundProcessor* CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate, int channels);
+    static SoundProcessor* CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate, int channels,
+                                            bool* engine_fault);
 public:
     ~SoundProcessor();
 
@@ -114,6 +116,7 @@ public:
     bool ConfigStillUpToDate() const;
 
     int block_size() const { return zita_config_.fragm; }
+    int frames_wanted() const { return zita_config_.fragm - input_pos_; }   // what the reference's FillBuffer would ask its file for now
     int run_ahead() const { return run_depth_; }         // this processor's run-ahead depth in blocks
     fe_stream* stream() const { return stream_; }      // for batched submission
     fe_engine* engine() const { return zita_config_.engine; }
@@ -140,6 +143,8 @@ private:
     void SettleChunk(Chunk* c);                   // wait for its request; on failure: silence, ok_ = false
     void DrainRing();
     void ScanPeaks(const float* v, size_t n);
+    void EngineCallFailed();
+    void EngineCallSucceeded();
 
     const ZitaConfig zita_config_;
     const std::string config_file_;
@@ -165,6 +170,7 @@ private:
     float max_out_value_observed_;
     float max_abs_value_observed_;
     bool ok_;
+    const std::atomic<int>* const slot_health_;   // the router's state of this processor's GPU slot (0: healthy)
 };
 
 }  // namespace folve

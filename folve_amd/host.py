@@ -52,6 +52,11 @@ HOST_SYMBOLS = [
     ("fh_pin_thread_near_device", _i, [_i]),
     ("fh_router_device_count", _i, []),
     ("fh_router_live_streams", _i, [_i]),
+    ("fh_router_slot_state", _i, [_i]),
+    ("fh_router_slot_failures", _ll, [_i]),
+    ("fh_router_slot_engine", _vp, [_i]),
+    ("fh_router_health_policy", None, [_i, C.c_double]),
+    ("fh_router_report_failure", None, [_vp]),
 ]
 
 # zita-config.h:51

@@ -66,6 +66,11 @@ int fe_engine_create(int device, void *hip_stream, fe_engine **out);
 void fe_engine_destroy(fe_engine *e);
 int fe_engine_synchronize(fe_engine *e);
 int fe_engine_device(const fe_engine *e);
+/* Health check: one small kernel on the engine's stream and its result back on the host; 0 if the GPU answered.
+ * The reference has no counterpart (a CPU does not go away); its unit of failure handling is the processor the pool
+ * discards and re-creates (processor-pool.cc:71-77) — the host's GPU sharder asks this of a GPU whose calls failed
+ * before it sends new files there again. */
+int fe_engine_probe(fe_engine *e);
 /* The host CPUs next to HIP device `device` as the kernel lists them ("0-31,128-159": sysfs local_cpulist of the
  * device's PCI function), for hosts that place file threads and page-locked buffers on the GPU's NUMA node.
  * FE_ERR_UNSUPPORTED if the system does not say. */

@@ -32,7 +32,9 @@ int fh_config_load(fe_engine *engine, const char *config_file, int fsamp, int ch
 /* sound-processor.cc:34 SoundProcessor::Create (GPU chosen by the router); NULL on failure */
 fh_processor *fh_processor_create(const char *config_file, int samplerate, int channels);
 void fh_processor_destroy(fh_processor *p);
-/* FillBuffer (cc:76): reads min(frames_available, block - input_pos) frames from src; returns frames taken */
+/* FillBuffer (cc:76): reads min(frames_available, block - input_pos) frames from src; returns frames taken — never
+ * more than it returns, whatever the run-ahead setting (the processor is shown a source that ends with the block), so a
+ * caller may advance `src` by the return value.  This form therefore runs one block per engine call. */
 int fh_processor_fill_buffer(fh_processor *p, const float *src, int frames_available);
 /* The same, also telling how many frames of `src` the processor took: with run-ahead on it reads AHEAD of the
  * frames it returns (the source is a file with a position, as SNDFILE* is), so a caller that passes spans of one
@@ -104,6 +106,17 @@ int fh_pin_thread_near_device(int device);
 int fh_router_device_count(void);
 int fh_router_live_streams(int slot);
 int fh_router_cached_filters(void);                     /* committed filters held: one per (configuration, slot) in use */
+/* GPU health (folve_amd/csrc/host/device_router.h): 0 healthy, 1 suspect (a call failed there: new files prefer the other
+ * GPUs), 2 fenced (consecutive failures: no new files until a probe succeeds).  The reference's analogue is the pool's
+ * discard-and-recreate loop, processor-pool.cc:71-77; its fallback when no processor can be had is the unfiltered
+ * file, folve-filesystem.cc:78-88 — which one bad GPU of eight must not trigger. */
+int fh_router_slot_state(int slot);
+long long fh_router_slot_failures(int slot);            /* failures reported for the slot since the process started */
+fe_engine *fh_router_slot_engine(int slot);             /* NULL until the slot has been used */
+/* fence_after: consecutive failures that fence a slot (<= 0: leave); reprobe_seconds: how old the last look at a sick
+ * slot must be before an open probes it again (< 0: leave; 0: every open) */
+void fh_router_health_policy(int fence_after, double reprobe_seconds);
+void fh_router_report_failure(fe_engine *e);            /* what a processor reports when a call on `e` failed (tests) */
 
 #ifdef __cplusplus
 }

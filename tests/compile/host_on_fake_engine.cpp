@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../folve_amd/csrc/host/batch_scheduler.h"
+#include "../../folve_amd/csrc/host/device_router.h"
 #include "../../folve_amd/csrc/host/processor_pool.h"
 #include "../../folve_amd/csrc/host/sound_processor.h"
 #include "../../include/folve_engine.h"
@@ -45,6 +46,11 @@ struct fe_stream {
 struct fe_ticket {
     std::chrono::steady_clock::time_point ready;
 };
+
+// fault knobs of the fake, per device: what a sick GPU does to the router (the `router` scenario below)
+std::atomic<int> g_dead[16];            // every compute call, commit, stream open and probe on the device fails
+std::atomic<int> g_no_create[16];       // fe_engine_create fails
+std::atomic<int> g_probe_hangs_ms[16];  // fe_engine_probe sleeps this long before it answers
 
 namespace {
 thread_local std::string g_err;
@@ -96,13 +102,23 @@ void fir(fe_stream* s, const float* in, long long frames, float* out, float* blo
 extern "C" {
 const char* fe_last_error(void) { return g_err.c_str(); }
 int fe_device_count(void) { return 1; }
+static bool dead(const fe_engine* e) { return e && e->device >= 0 && e->device < 16 && g_dead[e->device].load() != 0; }
+int fe_engine_probe(fe_engine* e) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    const int ms = e->device < 16 ? g_probe_hangs_ms[e->device].load() : 0;
+    if (ms) std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+    return dead(e) ? fail(FE_ERR_DEVICE, "dead (fake)") : 0;
+}
 int fe_device_local_cpulist(int, char* buf, size_t size) { if (size) buf[0] = 0; return FE_ERR_UNSUPPORTED; }
 int fe_fragm_for_size(unsigned int maxsize) {
     unsigned int fragm = FE_MAXQUANT;
     while (fragm > FE_MINPART && fragm >= 2 * maxsize) fragm /= 2;
     return (int)fragm;
 }
-int fe_engine_create(int device, void*, fe_engine** out) { *out = new fe_engine(); (*out)->device = device; return 0; }
+int fe_engine_create(int device, void*, fe_engine** out) {
+    if (device >= 0 && device < 16 && g_no_create[device].load()) return fail(FE_ERR_DEVICE, "no such device (fake)");
+    *out = new fe_engine(); (*out)->device = device; return 0;
+}
 void fe_engine_destroy(fe_engine* e) { delete e; }
 int fe_engine_device(const fe_engine* e) { return e ? e->device : -1; }
 int fe_filter_create(fe_engine* e, int ninp, int nout, int maxsize, float, fe_filter** out) {
@@ -126,11 +142,15 @@ int fe_filter_link(fe_filter* f, int i1, int o1, int i2, int o2) {
     f->link[(size_t)(i2 * f->nout + o2)] = i1 * f->nout + o1;
     return 0;
 }
-int fe_filter_commit(fe_filter* f) { f->committed = true; return 0; }
+int fe_filter_commit(fe_filter* f) {
+    if (dead(f->eng)) return fail(FE_ERR_DEVICE, "dead (fake)");
+    f->committed = true; return 0;
+}
 void fe_filter_retain(fe_filter* f) { if (f) f->refs.fetch_add(1); }
 void fe_filter_release(fe_filter* f) { if (f && f->refs.fetch_sub(1) == 1) delete f; }
 int fe_filter_use_count(const fe_filter* f) { return f ? f->refs.load() : 0; }
 int fe_stream_open(fe_filter* f, int max_blocks, fe_stream** out) {
+    if (dead(f->eng)) return fail(FE_ERR_DEVICE, "dead (fake)");
     fe_stream* s = new fe_stream();
     s->f = f; s->max_blocks = max_blocks;
     s->hist.assign((size_t)f->ninp, std::vector<float>((size_t)f->size, 0.f));
@@ -152,6 +172,7 @@ long long fe_stream_blocks_done(const fe_stream* s) { return s ? s->blocks_done 
 int fe_stream_block_size(const fe_stream* s) { return s ? s->f->P : 0; }
 int fe_stream_process(fe_stream* s, const float* in, int valid, float* out, float* ps, float* pa) {
     if (!s || valid < 1 || valid > s->f->P) return fail(FE_ERR_PARAM, "bad block");
+    if (dead(s->f->eng)) return fail(FE_ERR_DEVICE, "dead (fake)");
     std::lock_guard<std::mutex> lk(g_engine_mu);
     fir(s, in, valid, out, nullptr);
     if (ps) *ps = s->peak_s;
@@ -159,6 +180,7 @@ int fe_stream_process(fe_stream* s, const float* in, int valid, float* out, floa
     return 0;
 }
 int fe_batch_process(fe_stream* const* ss, int n, const float* const* in, const long long* nf, float* const* out, int) {
+    if (n > 0 && dead(ss[0]->f->eng)) return fail(FE_ERR_DEVICE, "dead (fake)");
     std::lock_guard<std::mutex> lk(g_engine_mu);
     for (int i = 0; i < n; ++i) fir(ss[i], in[i], nf[i], out[i], nullptr);
     return 0;
@@ -177,6 +199,7 @@ int fe_batch_submit_peaks(fe_stream* const* ss, int n, const float* const* in, c
             return fail(FE_ERR_UNSUPPORTED, "buffer not bound");
     }
     if (k % 23 == 7) return fail(FE_ERR_DEVICE, "refused (fake)");     // nothing was enqueued
+    if (n > 0 && dead(ss[0]->f->eng)) return fail(FE_ERR_DEVICE, "dead (fake)");
     {
         std::lock_guard<std::mutex> lk(g_engine_mu);
         for (int i = 0; i < n; ++i) fir(ss[i], in[i], nf[i], out[i], block_peaks ? block_peaks[i] : nullptr);
@@ -227,6 +250,173 @@ double rms(const std::vector<float>& a, const std::vector<float>& b) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------- the router scenario (`host_fake <dir> router`)
+// Eight GPU slots, one of them sick in the ways a GPU can be: never comes up, fails its calls, hangs its probe.
+// What must hold (device_router.h; the reference's discard-and-recreate loop, processor-pool.cc:71-77, and its
+// pass-through fallback when no processor can be had, folve-filesystem.cc:78-88): no open returns NULL while any GPU
+// works, new files stop going to the sick one, the pool hands out no processor that lives there, and the slot is
+// back in service once it answers a probe.
+namespace {
+int g_fail = 0;
+#define EXPECT(cond, ...) do { if (!(cond)) { ++g_fail; fprintf(stderr, "router scenario, line %d: ", __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
+
+// one short file through a processor, as the handler's loop does; returns the rms against the direct form (1e9: engine failure)
+double one_file(folve::SoundProcessor* p, unsigned seed, const std::vector<std::vector<float>>& h) {
+    const int P = 64;
+    std::mt19937 rng(seed);
+    const size_t n = 3 * P + rng() % (5 * P);
+    std::vector<float> a(n * 2);
+    for (auto& v : a) v = (float)(rng() % 2001) / 1000.f - 1.f;
+    MemSource src(&a, 2);
+    MemSink out(2);
+    long long left = (long long)n;
+    p->Reset();                                      // (what ProcessorPool::Return does between files)
+    while (left) {
+        const int got = p->FillBuffer(&src);
+        if (got <= 0) return 1e9;
+        left -= got;
+        p->WriteProcessed(&out, got);
+    }
+    if (!p->ok()) return 1e9;
+    return rms(out.d, direct(a, 2, h));
+}
+
+int router_scenario(const std::string& dir, const std::vector<std::vector<float>>& h) {
+    setenv("FOLVE_AMD_DEVICES", "0,1,2,3,4,5,6,7", 1);
+    folve::DeviceRouter* R = folve::DeviceRouter::Default();
+    EXPECT(R->device_count() == 8, "8 slots expected, %d", R->device_count());
+    R->SetFenceAfter(3);
+    R->SetReprobeSeconds(0.3);
+    R->SetProbeWaitSeconds(0.25);
+    folve::SoundProcessor::SetRunAhead(4);
+    folve::ProcessorPool pool(64);
+    auto per_slot = [&] { std::vector<int> v; for (int s = 0; s < 8; ++s) v.push_back(R->live_streams(s)); return v; };
+    auto open_many = [&](int n, int threads, std::vector<folve::SoundProcessor*>* into) {
+        std::vector<std::thread> th;
+        std::mutex mu;
+        std::atomic<int> next{0}, nulls{0};
+        for (int t = 0; t < threads; ++t) th.emplace_back([&] {
+            while (next.fetch_add(1) < n) {
+                std::string err;
+                folve::SoundProcessor* p = pool.GetOrCreate(dir, 44100, 2, 16, &err);
+                if (!p) { nulls.fetch_add(1); fprintf(stderr, "open failed: %s\n", err.c_str()); continue; }
+                std::lock_guard<std::mutex> lk(mu);
+                into->push_back(p);
+            }
+        });
+        for (auto& x : th) x.join();
+        return nulls.load();
+    };
+
+    // 1. GPU 5 never comes up: 63 opens from 16 threads all succeed, 9 on each of the other seven, slot 5 is fenced
+    g_no_create[5] = 1;
+    std::vector<folve::SoundProcessor*> procs;
+    EXPECT(open_many(63, 16, &procs) == 0, "an open failed while seven GPUs work");
+    {
+        const std::vector<int> live = per_slot();
+        for (int s = 0; s < 8; ++s) EXPECT(live[(size_t)s] == (s == 5 ? 0 : 9), "slot %d holds %d streams", s, live[(size_t)s]);
+        EXPECT(R->slot_state(5) == folve::DeviceRouter::kFenced, "slot 5 state %d", (int)R->slot_state(5));
+    }
+    // 2. it comes up: after the re-probe interval the next open looks at it again and, healthy and empty, it takes the next nine
+    g_no_create[5] = 0;
+    std::this_thread::sleep_for(std::chrono::milliseconds(350));
+    EXPECT(open_many(1, 1, &procs) == 0, "an open failed");      // (this one probes; opens that arrive meanwhile pass the slot over)
+    EXPECT(open_many(8, 4, &procs) == 0, "an open failed");
+    EXPECT(R->slot_state(5) == folve::DeviceRouter::kHealthy && R->live_streams(5) == 9, "slot 5: state %d, %d streams",
+           (int)R->slot_state(5), R->live_streams(5));
+    // every processor computes
+    for (size_t i = 0; i < procs.size(); ++i) EXPECT(one_file(procs[i], (unsigned)i, h) <= 1e-6, "processor %zu", i);
+
+    // 3. GPU 2 starts failing its calls: its files get silence and say so, three of them fence the slot, the others never notice
+    g_dead[2] = 1;
+    int failed = 0;
+    for (size_t i = 0; i < procs.size(); ++i) {
+        const bool on2 = procs[i]->device() == 2;
+        const double e = one_file(procs[i], 1000u + (unsigned)i, h);
+        if (on2) { EXPECT(e == 1e9 && !procs[i]->ok(), "a file on the dead GPU did not fail"); ++failed; }
+        else EXPECT(e <= 1e-6 && procs[i]->ok(), "a file on a healthy GPU failed (device %d)", procs[i]->device());
+    }
+    EXPECT(failed == 9, "%d files on GPU 2", failed);
+    EXPECT(R->slot_state(2) == folve::DeviceRouter::kFenced, "slot 2 state %d after %lld failures", (int)R->slot_state(2), R->slot_failures(2));
+    // new files while it is fenced (and inside the re-probe interval most of the time; a probe says no anyway): never there, never NULL
+    std::vector<folve::SoundProcessor*> more;
+    EXPECT(open_many(21, 8, &more) == 0, "an open failed while seven GPUs work");
+    for (folve::SoundProcessor* p : more) EXPECT(p->device() != 2, "a new file went to the fenced GPU");
+    for (size_t i = 0; i < more.size(); ++i) EXPECT(one_file(more[i], 2000u + (unsigned)i, h) <= 1e-6, "new processor %zu", i);
+    {
+        const std::vector<int> live = per_slot();
+        for (int s = 0; s < 8; ++s) EXPECT(live[(size_t)s] == (s == 2 ? 9 : 12), "slot %d holds %d streams", s, live[(size_t)s]);
+    }
+    // 4. everything goes back to the pool: the nine of GPU 2 are discarded, the rest pooled; the pool hands out none of GPU 2
+    for (folve::SoundProcessor* p : procs) pool.Return(p);
+    for (folve::SoundProcessor* p : more) pool.Return(p);
+    procs.clear(); more.clear();
+    EXPECT(R->live_streams(2) == 0, "slot 2 still holds %d streams", R->live_streams(2));
+    EXPECT(pool.pooled_count(dir + "/filter-44100.conf") == 64, "pooled %zu", pool.pooled_count(dir + "/filter-44100.conf"));
+    EXPECT(open_many(64, 8, &procs) == 0, "an open failed");
+    for (folve::SoundProcessor* p : procs) EXPECT(p->device() != 2, "the pool handed out a processor of the fenced GPU");
+    // 5. a GPU that fails only after processors were pooled there: the pool's checkout discards them (its engine is fenced by then)
+    for (folve::SoundProcessor* p : procs) pool.Return(p);
+    procs.clear();
+    g_dead[6] = 1;
+    for (int i = 0; i < 3; ++i) R->ReportFailure(R->EngineIfCreated(6));
+    EXPECT(R->slot_state(6) == folve::DeviceRouter::kFenced, "slot 6 state %d", (int)R->slot_state(6));
+    EXPECT(open_many(64, 8, &procs) == 0, "an open failed");
+    for (folve::SoundProcessor* p : procs) EXPECT(p->device() != 6 && p->device() != 2, "a processor of a fenced GPU (%d) was handed out", p->device());
+    for (size_t i = 0; i < procs.size(); ++i) EXPECT(one_file(procs[i], 3000u + (unsigned)i, h) <= 1e-6, "processor %zu", i);
+    // 6. both recover: the next opens probe them and, empty, they fill up first
+    g_dead[2] = 0; g_dead[6] = 0;
+    std::this_thread::sleep_for(std::chrono::milliseconds(350));
+    EXPECT(open_many(1, 1, &more) == 0, "an open failed");        // probes both (one after the other: each is due)
+    EXPECT(open_many(7, 2, &more) == 0, "an open failed");
+    EXPECT(R->slot_state(2) == folve::DeviceRouter::kHealthy && R->slot_state(6) == folve::DeviceRouter::kHealthy, "states %d %d",
+           (int)R->slot_state(2), (int)R->slot_state(6));
+    int back = 0;
+    for (folve::SoundProcessor* p : more) back += p->device() == 2 || p->device() == 6;
+    EXPECT(back == 8, "%d of 8 new files on the recovered GPUs", back);
+    for (size_t i = 0; i < more.size(); ++i) EXPECT(one_file(more[i], 4000u + (unsigned)i, h) <= 1e-6, "recovered processor %zu", i);
+    // 7. a GPU whose probe hangs: the open does not wait for it beyond the probe wait, and goes elsewhere
+    g_dead[3] = 1;
+    for (int i = 0; i < 3; ++i) R->ReportFailure(R->EngineIfCreated(3));
+    g_probe_hangs_ms[3] = 1500;
+    std::this_thread::sleep_for(std::chrono::milliseconds(350));
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string err;
+        folve::SoundProcessor* p = pool.GetOrCreate(dir, 44100, 2, 16, &err);    // pool is empty for this config: a Create
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        EXPECT(p != NULL && p->device() != 3, "open during a hanging probe");
+        EXPECT(dt < 1.0, "the open waited %.2f s for a hanging probe", dt);
+        if (p) more.push_back(p);
+    }
+    g_probe_hangs_ms[3] = 0;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1500));                // let the late probe come home (it says no)
+    EXPECT(R->slot_state(3) == folve::DeviceRouter::kFenced, "slot 3 state %d", (int)R->slot_state(3));
+    // 8. every GPU dead: opens fail, at once, with the reference's message for an unusable configuration
+    for (folve::SoundProcessor* p : procs) delete p;
+    for (folve::SoundProcessor* p : more) delete p;
+    procs.clear(); more.clear();
+    for (int d = 0; d < 8; ++d) g_dead[d] = 1;
+    {
+        std::string err;
+        folve::SoundProcessor* p = pool.GetOrCreate(dir, 44100, 2, 16, &err);
+        EXPECT(p == NULL && err == "Problem parsing " + dir + "/filter-44100.conf", "all GPUs dead: %p '%s'", (void*)p, err.c_str());
+        for (int s = 0; s < 8; ++s) EXPECT(R->live_streams(s) == 0, "slot %d keeps %d reservations", s, R->live_streams(s));
+    }
+    // ... and one comes back
+    g_dead[4] = 0;
+    std::this_thread::sleep_for(std::chrono::milliseconds(350));
+    {
+        std::string err;
+        folve::SoundProcessor* p = pool.GetOrCreate(dir, 44100, 2, 16, &err);
+        EXPECT(p != NULL && p->device() == 4, "one GPU back: %p", (void*)p);
+        if (p) { EXPECT(one_file(p, 5u, h) <= 1e-6, "the file on the GPU that came back"); delete p; }
+    }
+    printf("{\"router_scenario\": \"%s\", \"failed_checks\": %d}\n", g_fail ? "bad" : "ok", g_fail);
+    return g_fail ? 1 : 0;
+}
+}  // namespace
+
 int main(int argc, char** argv) {
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
     const int nthreads = argc > 2 ? atoi(argv[2]) : 8, rounds = argc > 3 ? atoi(argv[3]) : 6;
@@ -239,6 +429,7 @@ int main(int argc, char** argv) {
     }
     std::vector<std::vector<float>> h(2, std::vector<float>(20, 0.f));
     h[0][0] = 0.5f; h[0][7] = 0.25f; h[1][3] = -0.75f; h[1][19] = 0.125f;
+    if (argc > 2 && std::string(argv[2]) == "router") return router_scenario(dir, h);
     std::atomic<long long> bad{0}, files{0};
     folve::ProcessorPool pool(3);
     const int P = 64;

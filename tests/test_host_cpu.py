@@ -395,3 +395,11 @@ def test_host_layer_on_a_fake_engine_under_sanitizers(tmp_path, sanitizer):
     import json
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out == {"files": 96, "bad": 0}
+    # the GPU sharder's failure handling on the same binary: eight slots, one never comes up / fails its calls / hangs its
+    # probe — no open fails while any GPU works, the sick slot is fenced and gets no new files, the pool hands out nothing
+    # that lives there, a probe brings it back (device_router.h; the reference: processor-pool.cc:71-77, folve-filesystem.cc:78-88)
+    r = subprocess.run([exe, work, "router"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"router_scenario": "ok", "failed_checks": 0}

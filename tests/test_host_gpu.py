@@ -459,3 +459,80 @@ def test_a_touched_impulse_file_makes_processors_and_filters_stale(oracle, tmp_p
     fresh, _ = pool.get_or_create(d, 44100, 2, 16)                     # the pooled one is stale too: dropped, a new one built
     assert fresh is not None and fresh.config_still_up_to_date() and pool.pooled_count(conf) == 0
     assert np.array_equal(fresh.run(x), y)                             # same taps, rebuilt
+
+
+def test_span_fill_buffer_takes_exactly_what_it_returns(oracle, tmp_path):
+    """include/folve_host.h: fh_processor_fill_buffer (the span form of FillBuffer, sound-processor.cc:76-84) reads
+    min(frames_available, block - input_pos) frames and returns that number — with run-ahead on as well: a C host hands it
+    a span of MANY blocks and advances its pointer by the return value.  (Round 3's form read ahead of what it returned.)"""
+    import ctypes as C
+    d, hs = make_santalucia_shaped_dir(tmp_path)
+    H.set_run_ahead(16)
+    try:
+        sp = H.SoundProcessor.create(os.path.join(d, "filter-44100.conf"), 44100, 2)
+    finally:
+        H.set_run_ahead(H.AUTO_RUN_AHEAD)
+    assert sp is not None and sp.run_ahead() == 16
+    L = H._L()
+    x = seeded_input(31, 9 * 8192 + 4321, 2)
+    outs, done, returns = [], 0, []
+    while done < x.shape[0]:
+        span = x[done:]                                       # everything that is left, every time
+        r = L.fh_processor_fill_buffer(sp.h, span.ctypes.data_as(C.c_void_p), span.shape[0])
+        assert 0 < r <= 8192
+        returns.append(r)
+        outs.append(sp.write_processed(r))
+        done += r                                             # ... advanced by the return value, as the header says
+    assert returns == [8192] * 9 + [4321]
+    y = np.concatenate(outs, 0)
+    assert oracle.rms(y - oracle.linear_convolution_f64(x, hs, 2)) <= TOL
+    # partial fills of one block (the gapless top-up pattern): still exactly what was asked for
+    sp.reset()
+    a = L.fh_processor_fill_buffer(sp.h, x.ctypes.data_as(C.c_void_p), 1000)
+    b = L.fh_processor_fill_buffer(sp.h, x[1000:].ctypes.data_as(C.c_void_p), x.shape[0] - 1000)
+    assert (a, b) == (1000, 7192) and sp.is_input_buffer_complete()
+    z = sp.write_processed(8192)
+    assert oracle.rms(z - y[:8192]) <= 2e-6
+
+
+def test_router_health_on_the_only_gpu(oracle, tmp_path):
+    """folve::DeviceRouter with ONE slot (this process): calls that fail make the slot suspect, three in a row fence it —
+    and since it is the only GPU, the next open probes it at once instead of giving up: while the engine still fails the
+    open fails with the reference's message (processor-pool.cc:85), as soon as it answers again the slot is back.
+    The eight-slot case runs in tests/test_multi_gpu.py (cfg5's shape) and, without a GPU, in tests/test_host_cpu.py."""
+    import ctypes as C
+    d = make_echo_filter_dir(tmp_path)
+    L = H._L()
+    assert L.fh_router_device_count() >= 1
+    pool = H.ProcessorPool(3)
+    p, err = pool.get_or_create(d, 44100, 2, 16)
+    assert p is not None, err
+    eng = L.fh_processor_engine(p.h)
+    slot = [s for s in range(L.fh_router_device_count()) if L.fh_router_slot_engine(s) == eng][0]
+    assert L.fh_router_slot_state(slot) == 0
+    x = seeded_input(5, 4 * 8192, 2)
+    before = L.fh_router_slot_failures(slot)
+    try:
+        assert L.fe_engine_set_tuning(C.c_void_p(eng), 4, -1) == 0   # FE_TUNE_FAIL_NEXT: every launch round fails
+        assert L.fe_engine_probe(C.c_void_p(eng)) != 0
+        z = p.run(x)
+        assert not z.any() and L.fh_processor_ok(p.h) == 0
+        assert L.fh_router_slot_failures(slot) - before >= 3 and L.fh_router_slot_state(slot) == 2    # fenced
+        pool.give_back(p)
+        live = L.fh_router_live_streams(slot)                        # (processors of earlier tests may still be alive)
+        q, err = pool.get_or_create(d, 44100, 2, 16)                 # the only GPU: probed at once, still dead
+        assert q is None and err.startswith("Problem parsing ")
+        assert L.fh_router_live_streams(slot) == live                # no reservation left behind
+    finally:
+        assert L.fe_engine_set_tuning(C.c_void_p(eng), 4, 0) == 0
+    assert L.fe_engine_probe(C.c_void_p(eng)) == 0
+    q, err = pool.get_or_create(d, 44100, 2, 16)                     # probed again, answers: back in service
+    assert q is not None, err
+    assert L.fh_router_slot_state(slot) == 0
+    g = golden("echo")
+    y = q.run(x)
+    ref = 0.7 * x.astype(np.float64)
+    dl = int(g["delay_44100"])
+    ref[dl:] += 0.3 * x[:-dl].astype(np.float64)
+    assert oracle.rms(y - ref) <= TOL
+    pool.give_back(q)

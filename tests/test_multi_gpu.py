@@ -33,6 +33,34 @@ def test_two_router_slots_share_the_load(tmp_path):
     assert out["pooled"] == 8
 
 
+def test_cfg5_shape_eight_slots_512_streams_and_one_gpu_going_bad(tmp_path):
+    """BASELINE.json configs[4] on one device: eight router slots, 512 SoundProcessors of cfg3's filter opened through
+    ProcessorPool from 64 threads (64 per slot exactly), all 512 converting at once with spot parity against float64;
+    then one slot's engine fails every call: its files fail and say so, the slot is fenced, the next opens land on the
+    other seven and none returns NULL, the pool discards that slot's processors only; when the engine works again a
+    probe puts the slot back in service.  (tests/cfg5_worker.py; /root/reference/processor-pool.cc:48-91)"""
+    env = dict(os.environ, FOLVE_AMD_DEVICES="0,0,0,0,0,0,0,0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cfg5_worker.py"), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("CFG5_JSON ")][-1][len("CFG5_JSON "):])
+    bad = out["bad_slot"]
+    assert out["slots"] == 8 and out["distinct_engines"] == 8
+    assert out["live"] == [64] * 8 and out["per_slot"] == [64] * 8              # cfg5: 64 streams per GPU
+    assert out["cached_filters"] == 8                                            # one committed filter per slot
+    assert out["checked"] >= 12 and out["max_rms"] <= 1e-5
+    assert out["ok_before"] == 512 and out["states_before"] == [0] * 8
+    # one GPU bad: exactly its 64 files failed, the slot is fenced, the others never noticed
+    assert out["ok_after_per_slot"] == [0 if s == bad else 64 for s in range(8)]
+    assert out["states_bad"] == [2 if s == bad else 0 for s in range(8)] and out["failures_bad"] >= 3
+    assert out["more_null"] == 0 and out["more_on_bad"] == 0 and out["rms_more"] <= 1e-5
+    assert out["live_more"] == [64 if s == bad else 72 for s in range(8)]
+    assert out["pooled"] == 512 + 56 - 64 and out["live_pooled"][bad] == 0       # only the bad slot's processors were discarded
+    assert out["again_on_bad"] == 0
+    # and back in service
+    assert out["state_back"] == 0 and out["back_on_bad"] == 8 and out["rms_back"] <= 1e-5
+
+
 def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
