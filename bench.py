@@ -30,8 +30,10 @@ contract's keys:
   single_block_us — one synchronous stereo block through fe_stream_process (the drop-in call)
   drop_in_threads — the same call from 1 / 16 / 64 host threads at once, each its own folve::SoundProcessor
                  (a C++ child process over include/folve_host.h), with and without the per-GPU combiner
-  configs      — cfg2 (one stereo stream, SantaLucia shape) and cfg4 (96 kHz x 8 channels x 512 k taps) at 256-block
-                 calls: rate, per-kernel ms and roofline (PMC bytes of `bench.py --only-config cfgN`, profiles/traffic.json)
+  configs      — cfg1 (the lowpass demo shape, a 60 s file), cfg2 (one stereo stream, SantaLucia shape) and cfg4 (96 kHz x
+                 8 channels x 512 k taps) at 256-block calls: rate, per-kernel ms and roofline (PMC bytes of
+                 `bench.py --only-config cfgN`, profiles/traffic.json), each with the CPU path on the same shape (`cpu`)
+  mixed_filters — 64 streams over 4 filters (K = 8/25/32/64) in one call against 64 streams of one filter
   cpu_baseline — the CPU restatement of zita-convolver's algorithm (oracle/, rebuilt -march=native
                  on this box), all cores and one core, on a bounded sample (N = 1 only)
 """
@@ -191,6 +193,12 @@ def rms(a):
 # The other single-GPU configurations of BASELINE.json (parity-test shapes: tests/test_configs_gpu.py), measured the same
 # way as the headline: PCM resident in HBM, T-block run-ahead calls, HIP events per kernel.
 OTHER_CONFIGS = {
+    "cfg1": dict(S=1, C=2, size=65536, populated=123, rate=44100, frames=2646000, gpu_ref=False,
+                 what="one 44.1 kHz stereo file of 60 s (2 646 000 frames = 322 blocks + one of 8 176 frames) through the shape of "
+                      "demo-filters/lowpass (a 123-tap FIR in a 65 536-frame impulse file: size 65 536, K = 8, every partition "
+                      "populated as zita's impdata_create populates them; /root/reference/demo-filters/lowpass/filter-44100.conf, "
+                      "README.md:358-361) — BASELINE.json configs[0], the reference's own CPU-runnable case: the CPU figures are the "
+                      "point, the GPU rate of the same filter stands beside them"),
     "cfg2": dict(S=1, C=2, size=204800, populated=178193, rate=44100,
                  what="one 44.1 kHz stereo stream, SantaLucia-shaped filter (178 193 taps at delay 500 + a dirac, size 204 800: "
                       "K = 25, 22 populated; /root/reference/demo-filters/SantaLucia/filter-44100.conf:39-53)"),
@@ -199,7 +207,7 @@ OTHER_CONFIGS = {
 }
 
 
-def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=None, dev=0, check=True, **_):
+def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=None, dev=0, check=True, frames=None, **_):
     """One filter of C diagonal paths (`populated` taps at offset 500 plus a dirac at 0, or `size` dense taps), S streams,
     T-block calls.  Returns ms per call (wall clock over `steps` asynchronous calls), per-kernel ms (HIP events, a second
     loop), and — check=True — the rms deviation of the first call's output from the float64 convolution."""
@@ -215,7 +223,13 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
     taps = []
     for c in range(C):
         h = np.zeros(size, np.float32)
-        if populated:
+        if populated and populated < 4096:
+            # a short FIR in a long impulse file (the lowpass demo): /impulse/read hands the engine the WHOLE file, zeros
+            # included, and every partition the index range touches is populated
+            ir = rng.standard_normal(populated).astype(np.float32)
+            h[:populated] = ir / np.linalg.norm(ir)
+            flt.add(c, c, h)
+        elif populated:
             ir = (rng.standard_normal(populated) * np.exp(-np.arange(populated) / 40000.0)).astype(np.float32)
             h[500:500 + populated] = ir / np.linalg.norm(ir)
             h[0] += np.float32(0.4)
@@ -228,11 +242,14 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
         taps.append(h)
     flt.commit()
     P, K = flt.block_size, flt.partitions
+    if frames:
+        T = (frames + P - 1) // P                        # a whole file per call, its last block short
+    nfr = frames or T * P
     streams = [flt.open_stream(T) for _ in range(S)]
     with torch.cuda.stream(ts):
-        xs = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
+        xs = [torch.rand(nfr, C, device="cuda") * 2 - 1 for _ in range(S)]
         ys = [torch.empty_like(x) for x in xs]
-    plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S, FE_DEVICE_PTRS | FE_ASYNC)
+    plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [nfr] * S, FE_DEVICE_PTRS | FE_ASYNC)
     parity = None
     if check:
         plan.run()
@@ -262,21 +279,121 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
     eng.set_profiling(False)
     kms = {k: v["ms"] / max(1, v["launches"]) for k, v in prof.items()}
     out = {"streams": S, "channels": C, "taps": size, "block": P, "partitions": K, "populated_partitions": flt.path_partitions(0, 0),
-           "blocks_per_call": T, "ms_per_call": dt * 1e3, "kernels_ms": kms, "msamples_per_s": S * T * P * C / dt / 1e6,
-           "parity_rms": parity}
+           "blocks_per_call": T, "ms_per_call": dt * 1e3, "kernels_ms": kms, "msamples_per_s": S * nfr * C / dt / 1e6,
+           "frames_per_call": nfr, "parity_rms": parity}
     for s_ in streams:
         s_.close()
     del xs, ys
     return out
 
 
-def config_line(name, T, steps=100, tune=None, dev=0, check=True):
+def measure_mixed_filters(dev=0, T=64, steps=60, warmup=8, sizes=(65536, 204800, 262144, 524288), per_filter=16):
+    """Batches that mix filters: the reference resolves a configuration per sampling rate / channels / bits
+    (/root/reference/processor-pool.cc:53-61), so a music library keeps several filters live and a combined batch holds
+    streams of all of them.  64 stereo streams over 4 filters (K = 8 / 25 / 32 / 64) in ONE fe_batch_process call of
+    T-block run-ahead chunks, against 64 streams of the one K = 32 filter in the same kind of call (about the same
+    arithmetic: the mixed batch averages K = 32.25).  PCM resident in HBM; parity of one stream per filter against float64."""
+    import torch
+    import folve_amd as fa
+    from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS, FE_ASYNC
+    ts = torch.cuda.Stream()
+    eng = fa.Engine(dev, ts.cuda_stream)
+    rng = np.random.default_rng(11)
+    C = 2
+
+    def make_filter(size):
+        flt = fa.Filter(eng, C, C, size)
+        taps = []
+        for c in range(C):
+            h = rng.standard_normal(size).astype(np.float32)
+            h /= np.linalg.norm(h)
+            flt.add(c, c, h)
+            taps.append(h)
+        flt.commit()
+        return flt, taps
+
+    def run(filters, counts):
+        streams, taps_of = [], []
+        for (flt, taps), n in zip(filters, counts):
+            for _ in range(n):
+                streams.append(flt.open_stream(T))
+                taps_of.append(taps)
+        # interleave the filters' streams, as open files arrive in any order
+        order = sorted(range(len(streams)), key=lambda i: (i % per_filter, i // per_filter)) if len(filters) > 1 else list(range(len(streams)))
+        streams = [streams[i] for i in order]
+        taps_of = [taps_of[i] for i in order]
+        P = filters[0][0].block_size
+        with torch.cuda.stream(ts):
+            xs = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in streams]
+            ys = [torch.empty_like(x) for x in xs]
+        plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * len(streams), FE_DEVICE_PTRS | FE_ASYNC)
+        plan.run()
+        eng.synchronize()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for i in range(min(len(filters), len(streams))):         # the first stream of every filter (they are interleaved)
+            n = min(T, 12) * P
+            ref = conv_f64(xs[i][:n].cpu().numpy(), taps_of[i])
+            worst = max(worst, rms(ys[i][:n].cpu().numpy() - ref))
+        for _ in range(warmup):
+            plan.run()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan.run()
+        eng.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        for s_ in streams:
+            s_.close()
+        return {"ms_per_call": round(dt * 1e3, 4), "msamples_per_s": round(len(streams) * T * P * C / dt / 1e6, 1), "parity_rms": worst}
+
+    filters = [make_filter(sz) for sz in sizes]
+    mixed = run(filters, [per_filter] * len(sizes))
+    one = run([filters[2]], [per_filter * len(sizes)])
+    return {"what": "%d stereo streams over %d filters of %s taps (K = %s) in one %d-block-per-stream call, against %d streams of "
+                    "the %d-tap filter alone; PCM resident in HBM" % (per_filter * len(sizes), len(sizes), "/".join(str(z) for z in sizes),
+                                                                      "/".join(str(f[0].partitions) for f in filters), T,
+                                                                      per_filter * len(sizes), sizes[2]),
+            "mixed": mixed, "one_filter": one, "mixed_over_one_filter": round(mixed["msamples_per_s"] / one["msamples_per_s"], 3)}
+
+
+def cpu_for_config(cfg, budget=2.0):
+    """The CPU path on a configuration's shape (the CPU beside the GPU, same shape): the vectorised
+    stand-in (oracle/fastcpu.c) and the scalar parity oracle, ONE stream on one core — a configuration with one stream IS
+    one thread in folve's threading model (one synchronous engine per open file) — and, for context, as many such streams
+    as this process has CPUs.  Bounded: about `budget` seconds per configuration."""
+    from oracle import oracle as O      # the reported baseline, not the product
+    native = O.native_bench_lib() is not None
+    C, size = cfg["C"], cfg["size"]
+    P = O.fragm_for_size(size)
+    cores = usable_cpus()[0]
+    tp = O.fast_bench_streams(1, 4, 1, C, size, 3, native=native) / 4.0
+    nb = int(max(8, min(cfg.get("frames", 10 ** 9) // P + 1 if cfg.get("frames") else 4096, 0.35 * budget / max(tp, 1e-6))))
+    t1 = O.fast_bench_streams(1, nb, 1, C, size, 3, native=native)
+    nba = int(max(8, min(nb, 0.35 * budget / max(tp * 2.5, 1e-6))))
+    ta = O.fast_bench_streams(cores, nba, cores, C, size, 3, native=native)
+    nbs = int(max(4, min(nb, 0.3 * budget / max(tp * 3.0, 1e-6))))
+    ts_ = O.bench_streams(1, nbs, 1, C, C, size, 3, native=native)
+    return {"kind": "port", "what": "oracle/fastcpu.c (vectorised stand-in for zita-convolver, which is unavailable offline) on this "
+                                    "configuration's shape: %d channels, %d taps, partition %d, dense filter" % (C, size, P),
+            "one_stream_one_core": {"value": round(nb * P * C / t1 / 1e6, 2), "unit": "Msamples/s", "cores": 1,
+                                    "sample": "%d blocks, %.2f s" % (nb, t1),
+                                    "realtime_factor": round(nb * P / t1 / cfg["rate"], 1)},
+            "streams_on_all_cores": {"value": round(cores * nba * P * C / ta / 1e6, 2), "unit": "Msamples/s", "cores": cores,
+                                     "sample": "%d such streams x %d blocks, %d threads, %.2f s" % (cores, nba, cores, ta)},
+            "scalar_oracle_one_core": {"value": round(nbs * P * C / ts_ / 1e6, 2), "unit": "Msamples/s", "cores": 1,
+                                       "sample": "%d blocks, %.2f s" % (nbs, ts_)},
+            "build": "-O3 -march=native on this box" if native else "-O3 -march=x86-64-v3 (prebuilt)"}
+
+
+def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
     """The `configs` entry of one configuration: rate at T-block calls, per-kernel times, and its roofline — HBM bytes per
     launch from the committed rocprofv3 PMC passes of `python bench.py --only-config <name>` (profiles/traffic.json), used
     only while this run's kernel times agree with the profiled run's."""
     cfg = OTHER_CONFIGS[name]
     r = measure_config(T=T, steps=steps, tune=tune, dev=dev, check=check, **cfg)
     P, K, C, S = r["block"], r["partitions"], r["channels"], r["streams"]
+    T = r["blocks_per_call"]
     units = S * C * T
     tb = tiled_bytes(P, K, T)
     kms = r["kernels_ms"]
@@ -303,9 +420,21 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True):
                       "frac": round(by[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if by.get(k) else None,
                       "frac_of_min_bytes": round(tb[k] * units / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "kernel": (entry.get("kernels") or {}).get(k)}
+    cpu_leg = None
+    if cpu:
+        try:
+            cpu_leg = cpu_for_config(cfg)
+            one = cpu_leg["one_stream_one_core"]["value"]
+            cpu_leg["gpu_over_one_core"] = round(r["msamples_per_s"] / one, 1) if one else None
+        except Exception as e:  # noqa: BLE001
+            cpu_leg = {"error": repr(e)}
+    why_none = None
+    if not by:
+        why_none = note or "no PMC traffic profiled for this shape (profiles/traffic.json has no entry %s)" % ("S%d_T%d_K%d_C%d" % (S, T, K, C))
     return {"workload": "%s: %s; P=%d, %d blocks per call, PCM resident in HBM" % (name, cfg["what"], P, T),
             "msamples_per_s": round(r["msamples_per_s"], 1), "ms_per_call": round(r["ms_per_call"], 4),
-            "realtime_factor": round(T * P / (r["ms_per_call"] * 1e-3) / cfg["rate"], 0),
+            "realtime_factor": round(r["frames_per_call"] / (r["ms_per_call"] * 1e-3) / cfg["rate"], 0),
+            "cpu": cpu_leg,
             "blocks_per_call": T, "partitions": K, "populated_partitions": r["populated_partitions"],
             "parity_rms": r["parity_rms"],
             "roofline": {"bound": "hbm", "kernel": {"forward": "K1 forward", "mac": "K2 mac", "inverse": "K3 inverse"}[dominant],
@@ -313,6 +442,10 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dominant]["frac"], "traffic": by.get(dominant),
                          "traffic_source": entry.get("profile"), "traffic_note": note,
+                         # never "no roofline": without usable counter bytes the fraction by the MINIMUM bytes the call
+                         # must move (every real kernel moves at least those) is a lower bound of the true fraction
+                         "frac_lower_bound": kernels[dominant]["frac_of_min_bytes"],
+                         "frac_lower_bound_why": why_none or "counter bytes are available: `frac` is the measured fraction, this its floor",
                          "path": {"frac": round(path_bytes / (r["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if path_bytes else None,
                                   "traffic": path_bytes,
                                   "frac_of_min_bytes": round(tb["total"] * units / (r["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -334,8 +467,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the streaming / end-to-end / single-block legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU baseline sample length (all-core leg)")
     ap.add_argument("--tune", default="", help="engine tuning for experiments, e.g. mac_form=16,fwd_run=8")
-    ap.add_argument("--skip", default="", help="comma-separated extra legs to leave out: streaming,end_to_end,single_block,drop_in,configs")
-    ap.add_argument("--only-config", default="", choices=["", "cfg2", "cfg4"],
+    ap.add_argument("--skip", default="", help="comma-separated extra legs to leave out: streaming,end_to_end,single_block,drop_in,configs,mixed")
+    ap.add_argument("--only-config", default="", choices=["", "cfg1", "cfg2", "cfg4"],
                     help="run only this configuration's loop and print its `configs` entry (what tools/profile.sh profiles)")
     ap.add_argument("--config-blocks", type=int, default=256, help="blocks per call of the cfg2 / cfg4 legs")
     args = ap.parse_args()
@@ -521,6 +654,12 @@ def main():
                 "kernel_ms": round(kms[dominant], 4), "kernels_ms": {k: round(v, 4) for k, v in kms.items()},
                 "min_bytes_per_launch": int(tb[dominant] * units_per_launch),
                 "frac_of_min_bytes": round(tb[dominant] * units_per_launch / (kms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # never "no roofline": when the committed PMC traffic does not apply to this run (`frac` null, the reason in
+                # traffic_note) the fraction by the minimum bytes the launch must move still bounds the true one from below
+                "frac_lower_bound": round(tb[dominant] * units_per_launch / (kms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_lower_bound_why": ("`frac` is null: " + (traffic_note or "profiles/traffic.json has no entry for shape " + shape_key)
+                                         + "; this is min_bytes_per_launch / kernel time / peak, a floor of the true fraction")
+                if traffic is None else "counter bytes are in use: `frac` is the measured fraction, this its floor",
                 "frac_alg": {"applicable": T == 1, "value": round(frac_alg, 4),
                              "why": "SURVEY.md 8(d)'s streaming formula re-reads K spectra per output block; a "
                                     "run-ahead call re-uses them on chip, so this figure is not a roofline fraction"},
@@ -729,9 +868,16 @@ def main():
         configs = {}
         for name in OTHER_CONFIGS:
             try:
-                configs[name] = config_line(name, args.config_blocks, dev=dev)
+                configs[name] = config_line(name, args.config_blocks, dev=dev, cpu=not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 configs[name] = {"error": repr(e)}
+
+    mixed_filters = None
+    if extras and "mixed" not in skip:
+        try:
+            mixed_filters = measure_mixed_filters(dev=dev)
+        except Exception as e:  # noqa: BLE001
+            mixed_filters = {"error": repr(e)}
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -800,6 +946,7 @@ def main():
             "drop_in_threads": drop_in,
             "drop_in_threads_multi_gpu": (drop_in or {}).get("multi_gpu") if isinstance(drop_in, dict) else None,
             "configs": configs,
+            "mixed_filters": mixed_filters,
             "cpu_baseline": cpu,
         }
         if world > 1:

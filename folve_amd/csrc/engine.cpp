@@ -567,7 +567,10 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         HIP_TRY(hipStreamWaitEvent(e->lanes[l].st, e->dx_ev[c], 0));
         int rc = run_groups(e, streams, all, first[c], first[c + 1], l);
         if (rc) {
-            (void)hipStreamSynchronize(e->lanes[l ^ 1].st);     // earlier chunks still write into the callers' buffers
+            // earlier chunks still write into the callers' buffers — on BOTH lanes (chunks c - 2, c - 4, .. ran on this
+            // one, and a round that is refused before it enqueues anything does not drain its own lane)
+            (void)hipStreamSynchronize(e->lanes[l].st);
+            (void)hipStreamSynchronize(e->lanes[l ^ 1].st);
             (void)hipStreamSynchronize(e->cp_in);
             if (dma_out) (void)hipStreamSynchronize(e->cp_out);
             return rc;
