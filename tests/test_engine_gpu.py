@@ -137,6 +137,73 @@ def test_streams_of_two_filters_in_one_batch(engine, oracle):
     assert oracle.rms(yb - spb.run(xb)) <= TOL
 
 
+def test_streams_of_four_filters_ragged_in_one_batch_bit_identical_to_per_filter_calls(engine, oracle):
+    """A batch that mixes filters (the reference resolves one configuration per rate / channels / bits,
+    /root/reference/processor-pool.cc:53-61) is launched in per-filter groups — on both launch lanes when the call holds
+    several (engine.cpp run_groups).  Whatever lane a group lands on, its streams' outputs are the SAME BITS as when that
+    filter's streams are batched alone; 4 filters (K = 1 / 3 / 5 / 9), 3 streams each, ragged lengths, two calls with state
+    carried, through the host-pointer, the device-pointer and the submitted zero-copy forms."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77)
+    sizes = [3000, 20000, 40000, 70000]
+    filters, ref_procs = [], []
+    for size in sizes:
+        paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+        filters.append(paths)
+    lens = [[5 * 8192 + 77, 2 * 8192, 8192 - 5], [3 * 8192 + 1, 9 * 8192 + 4000, 100], [8192, 6 * 8192 + 3, 4 * 8192 + 4095]]
+    P_of = []
+    # inputs: [filter][stream] -> two consecutive calls
+    xs = []
+    for fi, size in enumerate(sizes):
+        row = []
+        for si in range(3):
+            n = lens[si][fi % 3] if size > 4096 else lens[si][fi % 3] // 2 + 13
+            row.append([rng.uniform(-1, 1, (n, 2)).astype(np.float32), rng.uniform(-1, 1, (n // 2 + 7, 2)).astype(np.float32)])
+        xs.append(row)
+
+    def fresh():
+        out = []
+        for fi, size in enumerate(sizes):
+            sp, flt, st = make_pair(engine, oracle, 2, 2, size, filters[fi], max_blocks=4)
+            more = [flt.open_stream(4) for _ in range(2)]
+            out.append((sp, flt, [st] + more))
+        return out
+
+    # (a) per filter, alone
+    alone = []
+    for fi, (sp, flt, sts) in enumerate(fresh()):
+        P_of.append(flt.block_size)
+        first = fa.batch_process(sts, [xs[fi][si][0] for si in range(3)])
+        second = fa.batch_process(sts, [xs[fi][si][1] for si in range(3)])
+        alone.append((first, second))
+        # (and right: the first stream against the oracle over both calls; a call's short last block is zero-padded —
+        # time advances by whole blocks — so the oracle sees the padded concatenation)
+        P = flt.block_size
+        a, b = xs[fi][0]
+        pad = (-len(a)) % P
+        both = np.concatenate([a, np.zeros((pad, 2), np.float32), b])
+        yo = sp.run(both)
+        assert oracle.rms(first[0] - yo[:len(a)]) <= TOL and oracle.rms(second[0] - yo[len(a) + pad:]) <= TOL
+    assert P_of == [4096, 8192, 8192, 8192]
+    # (b) all twelve streams interleaved in one call, host pointers
+    mixed = fresh()
+    order = [(fi, si) for si in range(3) for fi in range(4)]
+    sts = [mixed[fi][2][si] for fi, si in order]
+    y1 = fa.batch_process(sts, [xs[fi][si][0] for fi, si in order])
+    y2 = fa.batch_process(sts, [xs[fi][si][1] for fi, si in order])
+    for k, (fi, si) in enumerate(order):
+        assert np.array_equal(y1[k], alone[fi][0][si]) and np.array_equal(y2[k], alone[fi][1][si]), (fi, si)
+    # (c) the same through device pointers (what bench.py's mixed_filters leg times)
+    mixed = fresh()
+    sts = [mixed[fi][2][si] for fi, si in order]
+    for call in range(2):
+        xd = [torch.from_numpy(xs[fi][si][call]).cuda() for fi, si in order]
+        yd = [torch.empty_like(t) for t in xd]
+        fa.batch_process(sts, xd, yd, device=True)
+        for k, (fi, si) in enumerate(order):
+            assert np.array_equal(yd[k].cpu().numpy(), alone[fi][call][si]), (call, fi, si)
+
+
 def test_device_pointer_batch(engine, oracle):
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(13)
