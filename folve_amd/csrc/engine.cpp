@@ -128,6 +128,8 @@ struct fe_engine {
     std::vector<hipEvent_t> ticket_events;   // idle completion events of fe_batch_submit tickets
     hipEvent_t dx_ev[16] = {};               // run_duplex: "K1 of chunk c has finished"
     // profiling
+    hipEvent_t split_ev[4] = {};         // a lone stream's time tiles on two lanes: "K1 of tile c has finished"
+    int split_tiles = 0;                 // FE_TUNE_SPLIT: 0 automatic, 1 never, 2 .. 8 time tiles for a lone stream's long call
     int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none, < 0: every round)
     int sync_in_flight = 0;              // synchronous zero-copy calls waiting (lock released) on lane 0
     bool tuning_single_lane = false;     // FE_TUNE_LANES = 1: every submitted batch on lane 0 (measurements)
@@ -248,7 +250,11 @@ struct Item {
 // One launch round over streams that share a filter.  Host-side stream state (ring position, block
 // count) advances only after all three launches were accepted: a failed round leaves every stream
 // where it was.
-int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane, hipEvent_t after_k1 = nullptr) {
+//   after_k1 / before_k2: an event to record behind K1 / to wait for in front of K2 (a lone stream's time tiles on two
+//   lanes: tile c's K2 reads the spectra tile c - 1's K1 writes on the other lane); limit_blocks: at most so many blocks
+//   of every stream in this round (0: the stream's own bound).
+int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any, int lane, hipEvent_t after_k1 = nullptr,
+                 hipEvent_t before_k2 = nullptr, int limit_blocks = 0) {
     Lane& L = e->lanes[lane];
     hipStream_t st = L.st;
     const int P = f->P;
@@ -261,7 +267,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     for (Item& it : items) {
         if (it.left <= 0) continue;
         fe_stream* s = it.s;
-        const long long cap = (long long)s->max_blocks * P;
+        const long long cap = (long long)(limit_blocks > 0 ? std::min(limit_blocks, s->max_blocks) : s->max_blocks) * P;
         const long long take = std::min(it.left, cap);
         fk::StreamJob j{};
         j.in = it.in;
@@ -335,6 +341,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (after_k1) HIP_TRY(hipEventRecord(after_k1, st));
+    if (before_k2) HIP_TRY(hipStreamWaitEvent(st, before_k2, 0));
     if (prof) HIP_TRY(hipEventRecord(e->pev[1], st));
     HIP_TRY(fk::launch_mac(dj, nj, max_blocks, f->dev, L.Y, max_blocks, f->mac_shape, tn, st));
     if (prof) HIP_TRY(hipEventRecord(e->pev[2], st));
@@ -395,7 +402,26 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         groups.push_back(std::move(g));
     }
     const int other = lane ^ 1;
-    bool two = spread && groups.size() >= 2 && !after_k1 && !e->profiling && !e->tuning_single_lane && e->sync_in_flight == 0;
+    const bool lanes_ok = spread && !after_k1 && !e->profiling && !e->tuning_single_lane && e->sync_in_flight == 0;
+    bool two = lanes_ok && groups.size() >= 2;
+    // A LONE stream's long call (one open file converting far ahead; cfg2, cfg4): its three kernels are too small to fill
+    // the chip and a good part of the call is the launch chain itself — two dependency gaps, three launch ramps and
+    // tails.  The call's blocks are cut into time tiles whose K1 -> K2 -> K3 chains alternate between the two lanes: tile
+    // c's K2 needs the spectra of tile c - 1 (history), so it waits for that tile's K1 on the other lane, and nothing
+    // else — while tile c computes its products tile c + 1 transforms its PCM and tile c - 1 its results.
+    int split = 0;
+    // (not for PCM that crosses the bus under the kernels: a K1 reading page-locked memory beside a K3 writing it takes
+    // twice its time — reads queue behind posted writes)
+    if (lanes_ok && groups.size() == 1 && groups[0].items.size() == 1 && e->split_tiles != 1 && !e->host_io) {
+        const Item& it = groups[0].items[0];
+        const int P = groups[0].f->P;
+        const long long nb = (std::min<long long>(it.left, (long long)it.s->max_blocks * P) + P - 1) / P;
+        if (e->split_tiles >= 2) split = (int)std::min<long long>(e->split_tiles, nb);
+        // (automatic: never — measured on MI355X, cfg2 62 -> 88 us per 256-block call with two tiles, +14 .. 27 us per further
+        // tile: a cross-lane event wait costs more than the gap it hides; the knob stays for measurements)
+        if (split < 2) split = 0;
+    }
+    if (split) two = true;
     if (two) {
         if (!e->lanes[1].st) {
             HIP_TRY(hipStreamCreateWithFlags(&e->lanes[1].st, hipStreamNonBlocking));
@@ -413,6 +439,26 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         if (enqueued[0]) (void)hipStreamSynchronize(e->lanes[lane].st);
         if (enqueued[1]) (void)hipStreamSynchronize(e->lanes[other].st);
     };
+    if (split) {
+        if (!e->split_ev[0])
+            for (hipEvent_t& ev : e->split_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        Group& g = groups[0];
+        const int P = g.f->P;
+        bool any = true;
+        while (any) {                                           // (a span longer than the stream's bound: round after round)
+            const long long nb = (std::min<long long>(g.items[0].left, (long long)g.items[0].s->max_blocks * P) + P - 1) / P;
+            if (nb <= 0) break;
+            const int tiles = (int)std::min<long long>(split, nb);
+            const int tlen = (int)((nb + tiles - 1) / tiles);
+            for (int c = 0; c < tiles && any; ++c) {
+                const int side = c & 1;
+                hipEvent_t mine = e->split_ev[c % 4], prev = c ? e->split_ev[(c - 1) % 4] : nullptr;
+                int rc = launch_round(e, g.f, g.items, &any, side ? other : lane, mine, prev, tlen);
+                if (rc) { drain(); return rc; }
+                if (any) enqueued[side] = true;
+            }
+        }
+    } else
     for (Group& g : groups) {
         const int side = two && load[1] < load[0] ? 1 : 0;      // 0: `lane`, 1: the other one
         load[side] += g.work;
@@ -946,6 +992,11 @@ int fe_device_count(void) {
 
 int fe_fragm_for_size(unsigned int maxsize) {
     unsigned int fragm = FE_MAXQUANT;
+#ifdef FOLVE_EXPERIMENT_P16
+    // measurement build only (tools/build_p16.sh, tools/p16_experiment.py): every long filter at a 16 384-frame partition,
+    // at the boundary too — what a 16 384-point internal partition would do to K1 / K2 / K3
+    if (getenv("FOLVE_P16") && maxsize > 16384) return 16384;
+#endif
     while (fragm > FE_MINPART && fragm >= 2 * maxsize) fragm /= 2;
     return (int)fragm;
 }
@@ -1004,6 +1055,7 @@ static void engine_release(fe_engine* e) {
         if (e->ev_k[i]) (void)hipEventDestroy(e->ev_k[i]);
     }
     for (hipEvent_t ev : e->dx_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->split_ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->dx_k3) if (ev) (void)hipEventDestroy(ev);
     for (fe_engine::PeakBuf& pb : e->pkb) {
         if (pb.dev) (void)hipFree(pb.dev);
@@ -1589,7 +1641,7 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             e->tuning.mac_form = value;
             return FE_OK;
         case FE_TUNE_FFT_FORM:
-            if (value < 0 || value > 3) return fail(FE_ERR_PARAM, "FFT form must be 0, 1, 2 or 3");
+            if (value < 0 || value > 4) return fail(FE_ERR_PARAM, "FFT form must be 0 .. 4");
             e->tuning.fft_form = value;
             return FE_OK;
         case FE_TUNE_WALK_LPB:
@@ -1618,6 +1670,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             return FE_OK;
         case FE_TUNE_FAIL_NEXT:
             e->fail_round_in = value < 0 ? -1 : value;
+            return FE_OK;
+        case FE_TUNE_SPLIT:
+            if (value < 0 || value > 8) return fail(FE_ERR_PARAM, "split must be 0 (automatic), 1 (off) or 2 .. 8 time tiles");
+            e->split_tiles = value;
             return FE_OK;
         default:
             return fail(FE_ERR_PARAM, "unknown tuning knob %d", knob);

@@ -1890,6 +1890,9 @@ hipError_t dispatch_log2p(int log2P, A&&... a) {
         case 11: return Fn<11>::run(a...);
         case 12: return Fn<12>::run(a...);
         case 13: return Fn<13>::run(a...);
+#ifdef FOLVE_EXPERIMENT_P16
+        case 14: return Fn<14>::run(a...);
+#endif
         default: return hipErrorInvalidValue;
     }
 }
@@ -1909,7 +1912,7 @@ struct FwdLaunch {
         const JobRef jr = make_job_ref(jobs, tn);
         // Stereo fast forms, for launches that fill the chip (below that the per-channel kernel's
         // twice as many, half as long workgroups finish sooner).
-        const bool fast = tn.fft_form != 1 && f.cin == 2 && pairs_ok &&
+        const bool fast = tn.fft_form != 1 && f.cin == 2 && pairs_ok && !(tn.fft_form == 4 && (long long)njobs * max_blocks <= 512) &&
                           (tn.fft_form == 2 || (long long)njobs * max_blocks >= 256);
         if (fast) {
             if constexpr (L == 13) {
@@ -1918,7 +1921,7 @@ struct FwdLaunch {
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(WaveGeom<L>::NT);
                 hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jr, f, runlen, 0);
                 return hipGetLastError();
-            } else if constexpr (L >= 9) {                // 2P >= 1024: the one-transform stereo form exists
+            } else if constexpr (L >= 9 && L < 13) {      // 2P >= 1024: the one-transform stereo form exists
                 if (f.twa2) {
                     dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
                     hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jr, f);
@@ -1929,7 +1932,8 @@ struct FwdLaunch {
         if constexpr (L == 13) {
             // the one-block call from host memory: ONE 1024-thread workgroup, a half per channel, both
             // transforms at once (one workgroup per CU: latency is all that counts here)
-            if (tn.host_io && !tn.in_resident && tn.fft_form == 0 && f.cin == 2 && pairs_ok && (long long)njobs * max_blocks <= 64) {
+            if (((tn.host_io && !tn.in_resident && tn.fft_form == 0 && (long long)njobs * max_blocks <= 64) ||
+                 (tn.fft_form == 4 && (long long)njobs * max_blocks <= 512)) && f.cin == 2 && pairs_ok) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * WaveGeom<L>::NT);
                 hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, jr, f);
                 return hipGetLastError();
@@ -1972,7 +1976,8 @@ struct InvLaunch {
             // host_io: the output goes over the bus — the walker's whole 16-byte quads in full lines, not
             // the general kernel's interleaved 4-byte stores (27 us against ~12 for one stereo block)
             // the one-block call from host memory, stereo: both outputs at once in one 1024-thread workgroup
-            if (tn.host_io && tn.fft_form == 0 && pairs_ok && f.cout == 2 && (long long)njobs * max_blocks <= 64) {
+            if (((tn.host_io && tn.fft_form == 0 && (long long)njobs * max_blocks <= 64) ||
+                 (tn.fft_form == 4 && (long long)njobs * max_blocks <= 512)) && pairs_ok && f.cout == 2) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * NT);
                 hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, jr, f, Y);
                 return hipGetLastError();
@@ -2145,10 +2150,16 @@ void fill_fft_tables(int log2P, float2* dst, int off[4]) {
 namespace {
 struct WalkShape { int kr, lpb, tiles, tile_len, np; };
 // rows of G per lane for `lpb` lanes per bin: the smallest instantiated window that holds ceil(rows / lpb); 0: none
+// One lane per bin has a finer ladder (13 / 21 / 26 / 29 rows beside 9 / 17 / 33): a window wider than the filter multiplies
+// zeros — SantaLucia's 26 rows (K = 25) in the 33-row window were a fifth of a lone stream's K2 arithmetic.
 int walk_rows_per_lane(int rows, int lpb) {
     const int need = (rows + lpb - 1) / lpb;
     if (need <= 9 && lpb != 2) return 9;
+    if (lpb == 1 && need <= 13) return 13;
     if (need <= 17) return 17;
+    if (lpb == 1 && need <= 21) return 21;
+    if (lpb == 1 && need <= 26) return 26;
+    if (lpb == 1 && need <= 29) return 29;
     if (need <= 33) return 33;
     return 0;
 }
@@ -2226,7 +2237,11 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
             else launch_walk<33, 7, 4, 4>(jr, njobs, f, Y, ws, st);
         } else if (ws.lpb == 1) {
             if (ws.kr == 9) launch_walk<9, 7, 1>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 13) launch_walk<13, 7, 1>(jr, njobs, f, Y, ws, st);
             else if (ws.kr == 17) launch_walk<17, 7, 1>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 21) launch_walk<21, 7, 1>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 26) launch_walk<26, 7, 1>(jr, njobs, f, Y, ws, st);
+            else if (ws.kr == 29) launch_walk<29, 7, 1>(jr, njobs, f, Y, ws, st);
             else launch_walk<33, 7, 1>(jr, njobs, f, Y, ws, st);
         } else if (ws.lpb == 2) {
             if (ws.kr == 17) launch_walk<17, 15, 2>(jr, njobs, f, Y, ws, st);
