@@ -3,9 +3,16 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 namespace folve {
+
+namespace {
+std::atomic<const ImpulseOpener*> g_fallback{nullptr};
+}
+void ImpulseFile::SetFallbackOpener(const ImpulseOpener* opener) { g_fallback.store(opener); }
+const ImpulseOpener* ImpulseFile::FallbackOpener() { return g_fallback.load(); }
 
 namespace {
 uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
@@ -13,6 +20,10 @@ uint16_t le16(const unsigned char* p) { return static_cast<uint16_t>(p[0] | (p[1
 uint32_t be32(const unsigned char* p) { return p[3] | (p[2] << 8) | (p[1] << 16) | (static_cast<uint32_t>(p[0]) << 24); }
 uint16_t be16(const unsigned char* p) { return static_cast<uint16_t>(p[1] | (p[0] << 8)); }
 uint64_t be64(const unsigned char* p) { return (static_cast<uint64_t>(be32(p)) << 32) | be32(p + 4); }
+uint64_t le64(const unsigned char* p) { return (static_cast<uint64_t>(le32(p + 4)) << 32) | le32(p); }
+// Sony Wave64 chunk ids: a four-character code followed by this tail
+const unsigned char kW64Tail[12] = {0xf3, 0xac, 0xd3, 0x11, 0x8c, 0xd1, 0x00, 0xc0, 0x4f, 0x8e, 0xdb, 0x8a};
+const unsigned char kW64RiffTail[12] = {0x2e, 0x91, 0xcf, 0x11, 0xa5, 0xd6, 0x28, 0xdb, 0x04, 0xc1, 0x00, 0x00};
 // 80-bit IEEE 754 extended (AIFF sample rate)
 double ext80(const unsigned char* p) {
     const int sign = p[0] >> 7;
@@ -24,7 +35,7 @@ double ext80(const unsigned char* p) {
 }
 }  // namespace
 
-ImpulseFile::ImpulseFile() : f_(nullptr) { reset(); }
+ImpulseFile::ImpulseFile() : f_(nullptr), ext_(nullptr) { reset(); }
 ImpulseFile::~ImpulseFile() { close(); }
 
 void ImpulseFile::reset() {
@@ -35,23 +46,31 @@ void ImpulseFile::reset() {
     big_endian_ = signed8_ = false;
     size_ = pos_ = 0;
     data_offset_ = 0;
+    ext_ = nullptr;
 }
 
 int ImpulseFile::close() {
     if (f_) fclose(f_);
+    if (ext_) {
+        const ImpulseOpener* op = g_fallback.load();
+        if (op && op->close) op->close(ext_);
+    }
     reset();
     return 0;
 }
 
 int ImpulseFile::open_read(const char* name) {
-    if (f_) return ERR_MODE;
+    if (f_ || ext_) return ERR_MODE;
     reset();
     FILE* f = fopen(name, "rb");
     if (!f) return ERR_OPEN;
     unsigned char hdr[12];
     int rc = ERR_TYPE;
     if (fread(hdr, 1, 12, f) == 12) {
-        if (memcmp(hdr, "RIFF", 4) == 0 && memcmp(hdr + 8, "WAVE", 4) == 0) rc = open_wave(f);
+        if ((memcmp(hdr, "RIFF", 4) == 0 || memcmp(hdr, "RF64", 4) == 0 || memcmp(hdr, "BW64", 4) == 0) &&
+            memcmp(hdr + 8, "WAVE", 4) == 0) rc = open_wave(f);
+        else if (memcmp(hdr, "riff", 4) == 0 && memcmp(hdr + 4, kW64RiffTail, 8) == 0) rc = (fseek(f, 0, SEEK_SET) == 0) ? open_w64(f) : ERR_DATA;
+        else if (memcmp(hdr, ".snd", 4) == 0) rc = open_au(f, hdr);
         else if (memcmp(hdr, "FORM", 4) == 0 && memcmp(hdr + 8, "AIFF", 4) == 0) rc = open_aiff(f, false);
         else if (memcmp(hdr, "FORM", 4) == 0 && memcmp(hdr + 8, "AIFC", 4) == 0) rc = open_aiff(f, true);
         else if (memcmp(hdr, "caff", 4) == 0) rc = (fseek(f, 8, SEEK_SET) == 0) ? open_caf(f) : ERR_DATA;
@@ -59,6 +78,19 @@ int ImpulseFile::open_read(const char* name) {
     if (rc != ERR_NONE) {
         fclose(f);
         reset();
+        // not a container (or not an encoding) this reader decodes: whatever libsndfile opens is an impulse file to the
+        // reference (zita-audiofile.cc:51-99) — ask the registered decoder, if any
+        const ImpulseOpener* op = g_fallback.load();
+        if ((rc == ERR_TYPE || rc == ERR_FORM) && op && op->open) {
+            int r = 0, c = 0;
+            uint32_t n = 0;
+            void* h = op->open(name, &r, &c, &n);
+            if (h) {
+                if (c < 1) { if (op->close) op->close(h); return ERR_DATA; }
+                ext_ = h; rate_ = r; chan_ = c; size_ = n; pos_ = 0;
+                return ERR_NONE;
+            }
+        }
     }
     return rc;
 }
@@ -101,11 +133,20 @@ int ImpulseFile::finish_open(FILE* f, int bits, bool is_float, uint64_t data_byt
 int ImpulseFile::open_wave(FILE* f) {
     int tag = 0, bits = 0;
     bool have_fmt = false;
+    uint64_t data64 = 0;                  // RF64 / BW64: the 'data' chunk's real size, from 'ds64' (its 32-bit field says 0xffffffff)
+    bool have_ds64 = false;
     for (;;) {
         unsigned char ck[8];
         if (fread(ck, 1, 8, f) != 8) return ERR_DATA;
         const uint32_t len = le32(ck + 4);
-        if (memcmp(ck, "fmt ", 4) == 0) {
+        if (memcmp(ck, "ds64", 4) == 0) {
+            unsigned char b[24];                                    // riff size, data size, sample count (8 bytes each) [, table]
+            if (len < 24 || fread(b, 1, 24, f) != 24) return ERR_DATA;
+            data64 = le64(b + 8);
+            have_ds64 = true;
+            const long skip = static_cast<long>(len - 24) + (len & 1);
+            if (skip && fseek(f, skip, SEEK_CUR) != 0) return ERR_DATA;
+        } else if (memcmp(ck, "fmt ", 4) == 0) {
             unsigned char b[40];
             const uint32_t n = len < sizeof(b) ? len : static_cast<uint32_t>(sizeof(b));
             if (len < 16 || fread(b, 1, n, f) != n) return ERR_DATA;
@@ -121,11 +162,72 @@ int ImpulseFile::open_wave(FILE* f) {
         } else if (memcmp(ck, "data", 4) == 0) {
             if (!have_fmt || block_align_ < 1) return ERR_DATA;
             if (tag != 1 && tag != 3) return ERR_FORM;
-            return finish_open(f, bits, tag == 3, len);
+            return finish_open(f, bits, tag == 3, (len == 0xffffffffu && have_ds64) ? data64 : len);
         } else {
             if (fseek(f, static_cast<long>(len) + (len & 1), SEEK_CUR) != 0) return ERR_DATA;
         }
     }
+}
+
+// Sony Wave64: the RIFF/WAVE chunks with 16-byte GUID ids and 64-bit sizes that INCLUDE the 24-byte chunk header;
+// chunks are padded to 8 bytes.  The file starts with the 'riff' GUID, its size and the 'wave' GUID.
+int ImpulseFile::open_w64(FILE* f) {
+    unsigned char head[40];
+    if (fread(head, 1, 40, f) != 40 || memcmp(head + 24, "wave", 4) != 0 || memcmp(head + 28, kW64Tail, 12) != 0) return ERR_TYPE;
+    int tag = 0, bits = 0;
+    bool have_fmt = false;
+    for (;;) {
+        unsigned char ck[24];
+        if (fread(ck, 1, 24, f) != 24) return ERR_DATA;
+        const uint64_t len = le64(ck + 16);
+        if (len < 24 || memcmp(ck + 4, kW64Tail, 12) != 0) return ERR_DATA;
+        const uint64_t body = len - 24, pad = (8 - (len & 7)) & 7;
+        if (memcmp(ck, "fmt ", 4) == 0) {
+            unsigned char b[40];
+            const size_t n = body < sizeof(b) ? static_cast<size_t>(body) : sizeof(b);
+            if (body < 16 || fread(b, 1, n, f) != n) return ERR_DATA;
+            tag = le16(b);
+            chan_ = le16(b + 2);
+            rate_ = static_cast<int>(le32(b + 4));
+            block_align_ = le16(b + 12);
+            bits = le16(b + 14);
+            if (tag == 0xFFFE && n >= 26) tag = le16(b + 24);
+            if (fseek(f, static_cast<long>(body - n + pad), SEEK_CUR) != 0) return ERR_DATA;
+            have_fmt = true;
+        } else if (memcmp(ck, "data", 4) == 0) {
+            if (!have_fmt || block_align_ < 1) return ERR_DATA;
+            if (tag != 1 && tag != 3) return ERR_FORM;
+            return finish_open(f, bits, tag == 3, body);
+        } else {
+            if (fseek(f, static_cast<long>(body + pad), SEEK_CUR) != 0) return ERR_DATA;
+        }
+    }
+}
+
+// Sun / NeXT .au: big-endian header — magic, data offset, data size (0xffffffff: to the end), encoding, rate, channels.
+// Encodings 2 .. 7 are linear PCM of 8 / 16 / 24 / 32 bits and IEEE float / double; the companded ones (1 u-law, 27 A-law)
+// and ADPCM are left to the fallback opener.
+int ImpulseFile::open_au(FILE* f, const unsigned char* hdr12) {
+    unsigned char b[12];
+    if (fread(b, 1, 12, f) != 12) return ERR_DATA;
+    const uint32_t offset = be32(hdr12 + 4), bytes = be32(hdr12 + 8), enc = be32(b);
+    rate_ = static_cast<int>(be32(b + 4));
+    chan_ = static_cast<int>(be32(b + 8));
+    big_endian_ = true;
+    signed8_ = true;
+    int bits = 0;
+    bool is_float = false;
+    switch (enc) {
+        case 2: bits = 8; break;
+        case 3: bits = 16; break;
+        case 4: bits = 24; break;
+        case 5: bits = 32; break;
+        case 6: bits = 32; is_float = true; break;
+        case 7: bits = 64; is_float = true; break;
+        default: return ERR_FORM;
+    }
+    if (offset < 24 || fseek(f, static_cast<long>(offset), SEEK_SET) != 0) return ERR_DATA;
+    return finish_open(f, bits, is_float, bytes == 0xffffffffu ? ~static_cast<uint64_t>(0) : bytes);
 }
 
 // AIFF / AIFF-C: big-endian chunks; COMM = channels, frames, bits, 80-bit rate [, compression id]
@@ -216,6 +318,12 @@ int ImpulseFile::open_caf(FILE* f) {
 }
 
 int ImpulseFile::seek(uint32_t frame) {
+    if (ext_) {
+        const ImpulseOpener* op = g_fallback.load();
+        if (frame > size_ || !op || !op->seek || op->seek(ext_, frame) != 0) return ERR_SEEK;
+        pos_ = frame;
+        return 0;
+    }
     if (!f_) return ERR_MODE;
     if (frame > size_) return ERR_SEEK;
     if (fseek(f_, data_offset_ + static_cast<long>(frame) * block_align_, SEEK_SET) != 0) return ERR_SEEK;
@@ -224,6 +332,16 @@ int ImpulseFile::seek(uint32_t frame) {
 }
 
 int ImpulseFile::read(float* data, uint32_t frames) {
+    if (ext_) {
+        const ImpulseOpener* op = g_fallback.load();
+        if (!op || !op->read) return ERR_READ;
+        if (frames > size_ - pos_) frames = size_ - pos_;
+        if (!frames) return 0;
+        const int got = op->read(ext_, data, frames);
+        if (got < 0) return ERR_READ;
+        pos_ += static_cast<uint32_t>(got);
+        return got;
+    }
     if (!f_) return ERR_MODE;
     if (frames > size_ - pos_) frames = size_ - pos_;
     if (!frames) return 0;

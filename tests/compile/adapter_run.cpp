@@ -39,6 +39,13 @@ sf_count_t sf_writef_float(SNDFILE* f, const float* ptr, sf_count_t frames) {
     f->writes++;
     return frames;
 }
+// (the impulse-file fallback of the adapter wants these too; this binary's filters are WAVE files, read in-house:
+// tests/compile/impulse_fallback.cpp is where the fallback runs)
+struct SF_INFO { sf_count_t frames; int samplerate, channels, format, sections, seekable; };
+enum { SFM_READ = 0x10 };
+SNDFILE* sf_open(const char*, int, SF_INFO*) { return NULL; }
+sf_count_t sf_seek(SNDFILE*, sf_count_t, int) { return -1; }
+int sf_close(SNDFILE*) { return 0; }
 }
 #define FOLVE_AMD_SNDFILE_PROTOTYPES 1
 #include "../../folve_amd/csrc/host/sndfile_adapter.cpp"

@@ -19,11 +19,19 @@
 
 #include <string>
 
+#include <stdio.h>
+
 typedef struct SNDFILE_tag SNDFILE;
 typedef int64_t sf_count_t;
+struct SF_INFO { sf_count_t frames; int samplerate, channels, format, sections, seekable; };
+enum { SFM_READ = 0x10 };
 extern "C" {
 sf_count_t sf_readf_float(SNDFILE* sndfile, float* ptr, sf_count_t frames);
 sf_count_t sf_writef_float(SNDFILE* sndfile, const float* ptr, sf_count_t frames);
+// ... and the four the impulse-file fallback needs (zita-audiofile.cc:56,179-182)
+SNDFILE* sf_open(const char* path, int mode, SF_INFO* sfinfo);
+sf_count_t sf_seek(SNDFILE* sndfile, sf_count_t frames, int whence);
+int sf_close(SNDFILE* sndfile);
 }
 #define FOLVE_AMD_SNDFILE_PROTOTYPES 1
 #include "../../folve_amd/csrc/host/sndfile_adapter.cpp"

@@ -114,6 +114,81 @@ def write_caf(path, data, rate=44100, fmt="f32le", open_ended=False):
         f.write(b"caff" + struct.pack(">HH", 1, 0) + body)
 
 
+def _wav_body(data, fmt):
+    data = np.asarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    if fmt == "pcm16":
+        return np.clip(np.round(data * 32768.0), -32768, 32767).astype("<i2").tobytes(), 1, 16, data.shape[1]
+    if fmt == "pcm24":
+        v = np.clip(np.round(data * 8388608.0), -8388608, 8388607).astype("<i4")
+        return v.view(np.uint8).reshape(-1, 4)[:, :3].tobytes(), 1, 24, data.shape[1]
+    if fmt == "float32":
+        return data.astype("<f4").tobytes(), 3, 32, data.shape[1]
+    raise ValueError(fmt)
+
+
+def write_rf64(path, data, rate=44100, fmt="pcm16", magic=b"RF64"):
+    """RF64 / BW64 (EBU Tech 3306): RIFF with a 'ds64' chunk carrying the 64-bit sizes; the 32-bit fields say 0xffffffff."""
+    raw, tag, bits, ch = _wav_body(data, fmt)
+    align = ch * bits // 8
+    frames = len(raw) // align
+    ds64 = struct.pack("<QQQI", 36 + 28 + len(raw), len(raw), frames, 0)
+    with open(path, "wb") as f:
+        f.write(magic + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + b"ds64" + struct.pack("<I", len(ds64)) + ds64 +
+                b"fmt " + struct.pack("<IHHIIHH", 16, tag, ch, rate, rate * align, align, bits) +
+                b"data" + struct.pack("<I", 0xFFFFFFFF) + raw)
+
+
+_W64_TAIL = bytes([0xf3, 0xac, 0xd3, 0x11, 0x8c, 0xd1, 0x00, 0xc0, 0x4f, 0x8e, 0xdb, 0x8a])
+
+
+def write_w64(path, data, rate=44100, fmt="pcm16"):
+    """Sony Wave64: GUID chunk ids, 64-bit chunk sizes that include the 24-byte chunk header, chunks padded to 8 bytes."""
+    raw, tag, bits, ch = _wav_body(data, fmt)
+    align = ch * bits // 8
+
+    def chunk(cc, body):
+        b = cc + _W64_TAIL + struct.pack("<Q", 24 + len(body)) + body
+        return b + b"\0" * ((8 - len(b) % 8) % 8)
+    fmtc = chunk(b"fmt ", struct.pack("<HHIIHH", tag, ch, rate, rate * align, align, bits))
+    junk = chunk(b"junk", b"abcde")                             # an unknown chunk of odd size in front of the samples
+    datac = chunk(b"data", raw)
+    riff = b"riff" + bytes([0x2e, 0x91, 0xcf, 0x11, 0xa5, 0xd6, 0x28, 0xdb, 0x04, 0xc1, 0x00, 0x00])
+    wave = b"wave" + _W64_TAIL
+    total = 40 + len(fmtc) + len(junk) + len(datac)
+    with open(path, "wb") as f:
+        f.write(riff + struct.pack("<Q", total) + wave + fmtc + junk + datac)
+
+
+def write_au(path, data, rate=44100, fmt="pcm16", open_ended=False):
+    """Sun / NeXT .au, big-endian: pcm8 / pcm16 / pcm24 / pcm32 / float32 / float64 (encodings 2 .. 7)."""
+    data = np.asarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    ch = data.shape[1]
+    if fmt == "pcm8":
+        raw, enc = np.clip(np.round(data * 128.0), -128, 127).astype(np.int8).tobytes(), 2
+    elif fmt == "pcm16":
+        raw, enc = np.clip(np.round(data * 32768.0), -32768, 32767).astype(">i2").tobytes(), 3
+    elif fmt == "pcm24":
+        v = np.clip(np.round(data * 8388608.0), -8388608, 8388607).astype(">i4")
+        raw, enc = v.view(np.uint8).reshape(-1, 4)[:, 1:].tobytes(), 4
+    elif fmt == "pcm32":
+        raw, enc = np.clip(np.round(data * 2147483648.0), -2**31, 2**31 - 1).astype(">i4").tobytes(), 5
+    elif fmt == "float32":
+        raw, enc = data.astype(">f4").tobytes(), 6
+    elif fmt == "float64":
+        raw, enc = data.astype(">f8").tobytes(), 7
+    elif fmt == "ulaw":
+        raw, enc = bytes(len(data) * ch), 1                     # (content irrelevant: the reader must refuse it)
+    else:
+        raise ValueError(fmt)
+    note = b"folve test\0\0"                                     # annotation: the data offset is past the 24-byte header
+    with open(path, "wb") as f:
+        f.write(b".snd" + struct.pack(">IIIII", 24 + len(note), 0xFFFFFFFF if open_ended else len(raw), enc, rate, ch) + note + raw)
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, "demo_%s.npz" % name))
 

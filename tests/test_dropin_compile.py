@@ -23,6 +23,8 @@ def test_reference_call_sites_compile_against_the_dropin_classes(tmp_path):
     assert "T folve::SoundProcessor::FillBuffer(SNDFILE_tag*)" in syms
     assert "T folve::SoundProcessor::WriteProcessed(SNDFILE_tag*, int)" in syms
     assert "U sf_readf_float" in syms and "U sf_writef_float" in syms
+    # ... and the impulse-file fallback over sf_open / sf_seek / sf_close (zita-audiofile.cc:51-99,170-182)
+    assert "U sf_open" in syms and "U sf_seek" in syms and "U sf_close" in syms
 
 
 def test_library_itself_does_not_depend_on_libsndfile():

@@ -252,6 +252,105 @@ def test_loader_hilbert_copy_cd_quoting_and_formats(tmp_path, oracle):
     assert np.abs(y[:16000, 2] - h23).max() < 1e-6
 
 
+def test_loader_reads_rf64_w64_and_au_impulse_files(tmp_path):
+    """zita-audiofile.cc:51-99 takes whatever sf_open opens.  Beside WAVE / AIFF / CAF the loader reads the other
+    uncompressed containers itself — RF64 and BW64 (64-bit sizes in 'ds64'), Sony Wave64 (GUID chunks, 8-byte padding), Sun
+    .au (PCM 8 / 16 / 24 / 32, float, double) — normalised as sf_readf_float normalises; a companded .au is refused here
+    (it belongs to the fallback opener: tests/test_adapter_gpu.py)."""
+    from fixtures import write_au, write_rf64, write_w64
+    rng = np.random.default_rng(19)
+    ir = rng.uniform(-0.9, 0.9, (611, 3))
+    d = str(tmp_path)
+    files = []
+    for fmt, magic in (("pcm16", b"RF64"), ("pcm24", b"RF64"), ("float32", b"BW64")):
+        name = "r_%s_%s.wav" % (fmt, magic.decode())
+        write_rf64(os.path.join(d, name), ir, 48000, fmt, magic)
+        files.append((name, fmt))
+    for fmt in ("pcm16", "pcm24", "float32"):
+        write_w64(os.path.join(d, "w_%s.w64" % fmt), ir, 96000, fmt)
+        files.append(("w_%s.w64" % fmt, fmt))
+    for fmt in ("pcm8", "pcm16", "pcm24", "pcm32", "float32", "float64"):
+        write_au(os.path.join(d, "u_%s.au" % fmt), ir, 44100, fmt, open_ended=(fmt == "pcm24"))
+        files.append(("u_%s.au" % fmt, fmt))
+    text = "/convolver/new 1 %d 512 900\n" % len(files)
+    for k, (name, _) in enumerate(files):
+        text += "/impulse/read 1 %d 1.0 %d 7 0 3 %s\n" % (k + 1, k, name)      # offset 7, third channel, delay k
+    st, flt, z = H.config_load(_conf(tmp_path, text))
+    assert st == 0 and z["nout"] == len(files)
+
+    def q(scale, lo, hi):
+        return np.clip(np.round(ir * scale), lo, hi).astype(np.int64)
+    expect = {
+        "pcm8": q(128.0, -128, 127).astype(np.float32) / np.float32(128.0),
+        "pcm16": q(32768.0, -32768, 32767).astype(np.float32) / np.float32(32768.0),
+        "pcm24": (q(8388608.0, -8388608, 8388607) * 256).astype(np.float32) / np.float32(2147483648.0),
+        "pcm32": q(2147483648.0, -2**31, 2**31 - 1).astype(np.float32) / np.float32(2147483648.0),
+        "float32": ir.astype(np.float32), "float64": ir.astype(np.float32),
+    }
+    for k, (name, fmt) in enumerate(files):
+        h = np.zeros(900, np.float32)
+        h[k:k + 604] = expect[fmt][7:, 2]
+        assert np.array_equal(flt.taps(0, k, 900), h), name
+    # refused: u-law .au (an encoding for the fallback opener), an RF64 without its ds64, a Wave64 cut inside its header
+    write_au(os.path.join(d, "ulaw.au"), ir, 8000, "ulaw")
+    open(os.path.join(d, "nods64.wav"), "wb").write(b"RF64\xff\xff\xff\xffWAVEfmt \x10\0\0\0\1\0\1\0\x44\xac\0\0\x88\x58\1\0\2\0\x10\0data\xff\xff\xff\xff" + b"\1\0" * 10)
+    blob = open(os.path.join(d, "w_pcm16.w64"), "rb").read()
+    open(os.path.join(d, "cut.w64"), "wb").write(blob[:50])
+    for bad in ("ulaw.au", "cut.w64"):
+        st, flt, _ = H.config_load(_conf(tmp_path, "/convolver/new 1 1 512 900\n/impulse/read 1 1 1 0 0 0 1 %s\n" % bad))
+        assert st != 0 or flt.path_partitions(0, 0) == 0, bad
+    # (an RF64 whose data size is unknown is read to the end of the file, as libsndfile does)
+    st, flt, _ = H.config_load(_conf(tmp_path, "/convolver/new 1 1 512 900\n/impulse/read 1 1 1 0 0 0 1 nods64.wav\n"))
+    assert st == 0 and np.array_equal(flt.taps(0, 0, 12)[:10], np.full(10, 1.0 / 32768.0, np.float32))
+
+
+def test_impulse_files_the_reader_refuses_go_to_the_libsndfile_fallback(tmp_path):
+    """/root/reference/zita-audiofile.cc:51-99: an impulse file is whatever sf_open opens (FLAC, Ogg ..).  Where libsndfile
+    exists (a folve build) host/sndfile_adapter.cpp registers sf_open / sf_seek / sf_readf_float / sf_close as the loader's
+    fallback decoder.  tests/compile/impulse_fallback.cpp compiles the adapter against test-supplied sf_* (a made-up
+    container the in-house reader refuses), links the library and loads a configuration through the real loader: offset,
+    length, channel, gain and delay work as for a WAVE file; a WAVE file beside it is still read in-house; a file neither
+    side can open is skipped as the reference skips it (ERR_OTHER, zita-config.cc:345)."""
+    import json
+    import shutil
+    import struct
+    import subprocess
+    from fixtures import write_wav
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    import folve_amd as fa
+    libdir = os.path.dirname(fa.lib_path())
+    exe = os.path.join(str(tmp_path), "impulse_fallback")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "compile", "impulse_fallback.cpp"),
+                        "-o", exe, "-L" + libdir, "-lfolve_amd", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(23)
+    ir = rng.uniform(-1, 1, (300, 2)).astype(np.float32)
+    with open(os.path.join(str(tmp_path), "ir.toy"), "wb") as f:
+        f.write(b"TOY1" + struct.pack("<iii", 44100, 2, 300) + ir.astype("<f4").tobytes())
+    write_wav(os.path.join(str(tmp_path), "ir.wav"), np.round(ir * 32767).astype(np.int16), 44100)
+    open(os.path.join(str(tmp_path), "junk.bin"), "wb").write(b"neither a sound file nor a toy" * 4)
+    conf = _conf(tmp_path, "/convolver/new 1 4 64 400\n"
+                           "/impulse/read 1 1 0.5 3 10 100 2 ir.toy\n"       # gain, delay 3, offset 10, length 100, channel 2
+                           "/impulse/read 1 2 1.0 0 0 0 1 ir.toy\n"          # the whole file, channel 1
+                           "/impulse/read 1 3 1.0 0 0 0 1 ir.wav\n"          # in-house reader, no fallback involved
+                           "/impulse/read 1 4 1.0 0 0 0 1 junk.bin\n")       # nobody reads this: skipped
+    r = subprocess.run([exe, conf, "400"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["status"] == 0 and out["nout"] == 4
+    assert out["opens"] == 2 and out["closes"] == 2 and out["seeks"] == 1   # two .toy reads (one with an offset); the WAVE never got there
+    taps = np.array(out["taps"], np.float32)
+    h0 = np.zeros(400, np.float32)
+    h0[3:103] = np.float32(0.5) * ir[10:110, 1]
+    h1 = np.zeros(400, np.float32)
+    h1[:300] = ir[:, 0]
+    h2 = np.zeros(400, np.float32)
+    h2[:300] = np.round(ir[:, 0] * 32767).astype(np.int16).astype(np.float32) / np.float32(32768.0)
+    assert np.array_equal(taps[0], h0) and np.array_equal(taps[1], h1) and np.array_equal(taps[2], h2)
+    assert not taps[3].any()
+
+
 def test_loader_reads_aiff_and_caf_impulse_files(tmp_path):
     """zita-audiofile.cc:63-75 takes whatever libsndfile opens and names CAF and WAVEX; the loader
     reads the uncompressed AIFF / AIFF-C / CAF forms itself, normalised as sf_readf_float does."""
