@@ -13,10 +13,10 @@ FE_HOST_PTRS, FE_DEVICE_PTRS, FE_ASYNC = 0, 1, 2
 FE_K_FORWARD, FE_K_MAC, FE_K_INVERSE, FE_K_COUNT = 0, 1, 2, 3
 FE_TUNE_FWD_RUN, FE_TUNE_INV_RUN, FE_TUNE_MAC_FORM, FE_TUNE_FFT_FORM, FE_TUNE_FAIL_NEXT, FE_TUNE_LANES = 0, 1, 2, 3, 4, 5
 FE_TUNE_WALK_LPB, FE_TUNE_WALK_TILES, FE_TUNE_DUPLEX_OUT, FE_TUNE_DUPLEX_CHUNK_MB, FE_TUNE_DUPLEX_MIN_MB = 6, 7, 8, 9, 10
-FE_TUNE_SPLIT = 11
+FE_TUNE_SPLIT, FE_TUNE_DUPLEX_CAP_MB = 11, 12
 TUNE_KNOBS = {"fwd_run": FE_TUNE_FWD_RUN, "inv_run": FE_TUNE_INV_RUN, "mac_form": FE_TUNE_MAC_FORM,
               "fft_form": FE_TUNE_FFT_FORM, "fail_next": FE_TUNE_FAIL_NEXT, "lanes": FE_TUNE_LANES,
-              "walk_lpb": FE_TUNE_WALK_LPB, "walk_tiles": FE_TUNE_WALK_TILES, "duplex_out": FE_TUNE_DUPLEX_OUT, "duplex_chunk_mb": FE_TUNE_DUPLEX_CHUNK_MB, "duplex_min_mb": FE_TUNE_DUPLEX_MIN_MB, "split": FE_TUNE_SPLIT}
+              "walk_lpb": FE_TUNE_WALK_LPB, "walk_tiles": FE_TUNE_WALK_TILES, "duplex_out": FE_TUNE_DUPLEX_OUT, "duplex_chunk_mb": FE_TUNE_DUPLEX_CHUNK_MB, "duplex_min_mb": FE_TUNE_DUPLEX_MIN_MB, "split": FE_TUNE_SPLIT, "duplex_cap_mb": FE_TUNE_DUPLEX_CAP_MB}
 KERNEL_NAMES = ("forward", "mac", "inverse")
 
 

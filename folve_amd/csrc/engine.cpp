@@ -103,6 +103,7 @@ struct fe_engine {
     PeakBuf pkb[4];
     int pkb_next = 0;
     int duplex_chunk_mb = 0;             // FE_TUNE_DUPLEX_CHUNK_MB (0: 32)
+    int duplex_cap_mb = 0;               // FE_TUNE_DUPLEX_CAP_MB (0: 8192): a batch that needs more staging per direction keeps the zero-copy kernels
     int duplex_min_mb = 0;               // FE_TUNE_DUPLEX_MIN_MB (0: 32): smaller submitted batches keep the zero-copy kernels
     int duplex_out = 0;                  // 0 / 2: K3 -> device staging -> DMA out; 1: K3 stores into the callers' buffers
     hipEvent_t dx_free[2] = {};          // the batch that last used dx_stage[i] has finished
@@ -555,6 +556,7 @@ int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* c
 // buffers instead of the outbound copies.)  At the end `lane` (the one the caller records its completion event on)
 // waits for the other lane and for the last copy out.
 constexpr int kDuplexChunks = 16;
+constexpr size_t kDuplexStageCap = (size_t)8 << 30;      // per direction and parity: beyond it a batch keeps the zero-copy kernels
 struct DuplexPlan {
     int nc = 0;
     int first[kDuplexChunks + 1] = {};
@@ -597,13 +599,26 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         off[(size_t)i] = need;
         need += (((size_t)nframes[i] * streams[i]->f->ninp + 3) & ~(size_t)3) * sizeof(float);
     }
-    if (e->dx_stage_bytes[par] < need) {
-        if (e->dx_stage[par]) HIP_TRY(hipFree(e->dx_stage[par]));
-        e->dx_stage[par] = nullptr;
-        e->dx_stage_bytes[par] = 0;
-        HIP_TRY(hipMalloc((void**)&e->dx_stage[par], need + need / 4));
-        e->dx_stage_bytes[par] = need + need / 4;
-    }
+    // Staging follows the batches: it grows to 1.25 x the largest batch and is let go again when batches have become much
+    // smaller (a burst of 64 files x 64 stereo blocks leaves 0.6 GB per direction pair behind otherwise, for the life of the
+    // process).  A batch the staging cannot be had for does not fail: FE_ERR_UNSUPPORTED sends it down the zero-copy path.
+    auto fit_stage = [&](float*& buf, size_t& have, size_t want) -> int {
+        const bool too_small = have < want, far_too_big = have > ((size_t)256 << 20) && have > 4 * want;
+        if (!too_small && !far_too_big) return FE_OK;
+        if (buf) HIP_TRY(hipFree(buf));
+        buf = nullptr;
+        have = 0;
+        if (hipMalloc((void**)&buf, want + want / 4) != hipSuccess) {
+            (void)hipGetLastError();
+            buf = nullptr;
+            return fail(FE_ERR_UNSUPPORTED, "no device memory for %zu bytes of duplex staging: the batch runs zero-copy", want + want / 4);
+        }
+        have = want + want / 4;
+        return FE_OK;
+    };
+    const size_t stage_cap = e->duplex_cap_mb > 0 ? (size_t)e->duplex_cap_mb << 20 : kDuplexStageCap;
+    if (need > stage_cap) return fail(FE_ERR_UNSUPPORTED, "batch of %zu bytes exceeds the duplex staging cap: it runs zero-copy", need);
+    if (int rc = fit_stage(e->dx_stage[par], e->dx_stage_bytes[par], need)) return rc;
     size_t need_out = 0;
     std::vector<size_t> off_out((size_t)n);
     if (dma_out) {
@@ -611,13 +626,8 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
             off_out[(size_t)i] = need_out;
             need_out += (((size_t)nframes[i] * streams[i]->f->nout + 3) & ~(size_t)3) * sizeof(float);
         }
-        if (e->dx_stage_out_bytes[par] < need_out) {
-            if (e->dx_stage_out[par]) HIP_TRY(hipFree(e->dx_stage_out[par]));
-            e->dx_stage_out[par] = nullptr;
-            e->dx_stage_out_bytes[par] = 0;
-            HIP_TRY(hipMalloc((void**)&e->dx_stage_out[par], need_out + need_out / 4));
-            e->dx_stage_out_bytes[par] = need_out + need_out / 4;
-        }
+        if (need_out > stage_cap) return fail(FE_ERR_UNSUPPORTED, "batch of %zu bytes exceeds the duplex staging cap: it runs zero-copy", need_out);
+        if (int rc = fit_stage(e->dx_stage_out[par], e->dx_stage_out_bytes[par], need_out)) return rc;
     }
     struct HostOutScope {                // with the results leaving by DMA the kernels see device memory on both sides
         fe_engine* e; bool was;
@@ -882,6 +892,19 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
         if (pk_dev && !duplex) HIP_TRY(hipMemsetAsync(pk_dev, 0, pk_bytes, st));
         int rc = duplex ? run_duplex(e, streams, all, n, host_in, host_out, nframes, lane, dplan, pk_dev, pk_host, pk_bytes)
                         : run_groups(e, streams, all, 0, n, lane, nullptr, /*spread=*/true);
+        if (rc == FE_ERR_UNSUPPORTED && duplex) {
+            // no staging to be had (device memory, the cap): nothing has been enqueued — the batch runs on `lane` with the
+            // kernels reading and writing the callers' page-locked buffers, as small batches do
+            for (int i = 0; i < n; ++i) lane_of[(size_t)i] = lane;     // (the bookkeeping of the plan that was not carried out)
+            seqs[lane ^ 1] = 0;
+            if (seq_out) seq_out[lane ^ 1] = 0;
+            // (streams the plan had put on the other lane may have their last call there: everything it holds comes first)
+            HIP_TRY(hipEventRecord(e->lanes[lane ^ 1].xev, e->lanes[lane ^ 1].st));
+            HIP_TRY(hipStreamWaitEvent(st, e->lanes[lane ^ 1].xev, 0));
+            if (pk_dev) HIP_TRY(hipMemsetAsync(pk_dev, 0, pk_bytes, st));
+            rc = run_groups(e, streams, all, 0, n, lane, nullptr, /*spread=*/false);
+            if (!rc && pk_dev) HIP_TRY(hipMemcpyAsync(pk_host, pk_dev, pk_bytes, hipMemcpyDeviceToHost, st));
+        }
         if (rc) return rc;
         if (pk_dev && !duplex) HIP_TRY(hipMemcpyAsync(pk_host, pk_dev, pk_bytes, hipMemcpyDeviceToHost, st));
         if (!device_ptrs) {
@@ -1670,6 +1693,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             return FE_OK;
         case FE_TUNE_FAIL_NEXT:
             e->fail_round_in = value < 0 ? -1 : value;
+            return FE_OK;
+        case FE_TUNE_DUPLEX_CAP_MB:
+            if (value < 0 || value > (1 << 20)) return fail(FE_ERR_PARAM, "cap must be 0 .. 1048576 MB");
+            e->duplex_cap_mb = value;
             return FE_OK;
         case FE_TUNE_SPLIT:
             if (value < 0 || value > 8) return fail(FE_ERR_PARAM, "split must be 0 (automatic), 1 (off) or 2 .. 8 time tiles");

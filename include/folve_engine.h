@@ -195,6 +195,8 @@ enum {
     FE_TUNE_DUPLEX_OUT = 8,/* big submitted batches (PCM comes in by DMA): results leave 0 / 2 by DMA too, 1 by K3's stores into the callers' buffers */
     FE_TUNE_DUPLEX_CHUNK_MB = 9, /* ... and the pipeline's chunk size: megabytes of PCM (in + out) per chunk, at most 16 chunks (0: 32) */
     FE_TUNE_DUPLEX_MIN_MB = 10, /* ... and the smallest batch (megabytes of PCM in + out) that takes the pipeline (0: 32) */
+    FE_TUNE_DUPLEX_CAP_MB = 12, /* ... and the most device memory (megabytes per direction) the pipeline may stage a batch in (0: 8192); a
+                              batch beyond it, or one the memory cannot be had for, runs with the zero-copy kernels instead of failing */
     FE_TUNE_SPLIT = 11,    /* a lone stream's long call as time tiles whose K1 -> K2 -> K3 chains alternate between the two launch lanes:
                               0 automatic (2 tiles from 64 blocks on), 1 never, 2 .. 8 tiles */
     FE_TUNE_LANES = 5      /* fe_batch_submit: 1 = every batch on the engine's own HIP stream, 0 / 2 = two lanes (batches of different

@@ -604,3 +604,59 @@ def test_block_peaks_of_a_submitted_batch(tuned, oracle):
             s_.close()
         for b in bufs:
             L.fe_host_free(b)
+
+
+def test_a_batch_the_duplex_staging_cannot_hold_runs_zero_copy(tuned, oracle):
+    """engine.cpp run_duplex: the staging of the duplex pipeline is capped (FE_TUNE_DUPLEX_CAP_MB; 8 GB by default) and a
+    batch beyond the cap — or one the device memory cannot be had for — does not fail: it runs on the zero-copy kernels, on
+    one lane, with the same results within float32 rounding and the per-block maxima still delivered; a stream that then
+    goes on (state carried) in an ordinary duplex batch continues correctly, whichever lanes the two batches used."""
+    import ctypes
+    L = fa.lib()
+    size, C, S, nblk = 60000, 2, 40, 16                       # 40 x 16 stereo blocks: 42 MB each way, a duplex batch
+    rng = np.random.default_rng(321)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+    _, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+    P = flt.block_size
+    streams = [flt.open_stream(nblk) for _ in range(S)]
+    bufs, arrs = [], []
+    for s_ in streams:
+        b = ctypes.c_void_p()
+        assert L.fe_host_alloc(nblk * P * C * 4, ctypes.byref(b)) == 0
+        assert L.fe_stream_bind_host_buffer(s_.h, b, nblk * P * C * 4) == 0
+        bufs.append(b)
+        arrs.append(np.ctypeslib.as_array(ctypes.cast(b, ctypes.POINTER(ctypes.c_float)), shape=(nblk * P, C)))
+    x1 = [rng.uniform(-1, 1, (nblk * P, C)).astype(np.float32) for _ in range(S)]
+    x2 = [rng.uniform(-1, 1, (nblk * P, C)).astype(np.float32) for _ in range(S)]
+    ss = (ctypes.c_void_p * S)(*[s_.h for s_ in streams])
+    pp = (ctypes.c_void_p * S)(*[b.value for b in bufs])
+    nn = (ctypes.c_longlong * S)(*([nblk * P] * S))
+
+    def batch(xs):
+        pk = [np.full((nblk, 2), -7.0, np.float32) for _ in range(S)]
+        kk = (ctypes.c_void_p * S)(*[p.ctypes.data for p in pk])
+        for a, x in zip(arrs, xs):
+            a[:] = x
+        t = ctypes.c_void_p()
+        assert L.fe_batch_submit_peaks(ss, S, pp, nn, pp, kk, ctypes.byref(t)) == 0, L.fe_last_error()
+        assert L.fe_ticket_wait(t) == 0
+        return [a.copy() for a in arrs], pk
+
+    try:
+        tuned.set_tuning(duplex_cap_mb=8)                     # 8 MB: this batch cannot be staged
+        y1, pk1 = batch(x1)
+        tuned.set_tuning(duplex_cap_mb=0)
+        y2, pk2 = batch(x2)                                   # the ordinary duplex pipeline, state carried
+        for i in (0, 7, S - 1):
+            ref = oracle.linear_convolution_f64(np.concatenate([x1[i], x2[i]]), dense_taps(paths, size), C)
+            assert _rms(np.concatenate([y1[i], y2[i]]) - ref) <= TOL, i
+        for i in range(S):
+            for y, pk in ((y1[i], pk1[i]), (y2[i], pk2[i])):
+                yb = y.reshape(nblk, P * C)
+                assert np.array_equal(pk[:, 0], np.maximum(0.0, yb.max(axis=1))) and np.array_equal(pk[:, 1], np.abs(yb).max(axis=1)), i
+    finally:
+        tuned.set_tuning(duplex_cap_mb=0)
+        for s_ in streams:
+            s_.close()
+        for b in bufs:
+            L.fe_host_free(b)
