@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --skip drop_in,configs,end_to_end,single_block $@"   # bench.py defaults: 20 warm-up + 500 timed steps; the legs left out run child processes or other shapes
+ARGS="--no-cpu-baseline --skip drop_in,configs,end_to_end,single_block,mixed $@"   # bench.py defaults: 20 warm-up + 500 timed steps; the legs left out run child processes or other shapes
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py $ARGS > $OUT/bench_$c.log 2>&1
