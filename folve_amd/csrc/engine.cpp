@@ -94,6 +94,7 @@ struct fe_engine {
     size_t dx_stage_bytes[2] = {};
     float* dx_stage_out[2] = {};         // ... and output staging when the results leave by DMA too (FE_TUNE_DUPLEX_OUT = 2)
     size_t dx_stage_out_bytes[2] = {};
+    int dx_stage_idle[2] = {}, dx_stage_out_idle[2] = {};   // consecutive batches that needed less than a quarter of the staging
     hipEvent_t dx_k3[16] = {};           // "K3 of chunk c has finished"
     // per-block maxima of submitted batches (fe_batch_submit_peaks): a few rotating device / page-locked pairs
     struct PeakBuf {
@@ -602,9 +603,14 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
     // Staging follows the batches: it grows to 1.25 x the largest batch and is let go again when batches have become much
     // smaller (a burst of 64 files x 64 stereo blocks leaves 0.6 GB per direction pair behind otherwise, for the life of the
     // process).  A batch the staging cannot be had for does not fail: FE_ERR_UNSUPPORTED sends it down the zero-copy path.
-    auto fit_stage = [&](float*& buf, size_t& have, size_t want) -> int {
-        const bool too_small = have < want, far_too_big = have > ((size_t)256 << 20) && have > 4 * want;
+    auto fit_stage = [&](float*& buf, size_t& have, size_t want, int& idle) -> int {
+        const bool too_small = have < want;
+        // (let go only after 64 batches in a row that needed less than a quarter of it: a file's ramp 1, 2, 4 .. blocks
+        // alternates small batches with big ones, and hipFree / hipMalloc synchronise the device)
+        idle = (have > ((size_t)256 << 20) && have > 4 * want) ? idle + 1 : 0;
+        const bool far_too_big = idle >= 64;
         if (!too_small && !far_too_big) return FE_OK;
+        idle = 0;
         if (buf) HIP_TRY(hipFree(buf));
         buf = nullptr;
         have = 0;
@@ -618,7 +624,7 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
     };
     const size_t stage_cap = e->duplex_cap_mb > 0 ? (size_t)e->duplex_cap_mb << 20 : kDuplexStageCap;
     if (need > stage_cap) return fail(FE_ERR_UNSUPPORTED, "batch of %zu bytes exceeds the duplex staging cap: it runs zero-copy", need);
-    if (int rc = fit_stage(e->dx_stage[par], e->dx_stage_bytes[par], need)) return rc;
+    if (int rc = fit_stage(e->dx_stage[par], e->dx_stage_bytes[par], need, e->dx_stage_idle[par])) return rc;
     size_t need_out = 0;
     std::vector<size_t> off_out((size_t)n);
     if (dma_out) {
@@ -627,7 +633,7 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
             need_out += (((size_t)nframes[i] * streams[i]->f->nout + 3) & ~(size_t)3) * sizeof(float);
         }
         if (need_out > stage_cap) return fail(FE_ERR_UNSUPPORTED, "batch of %zu bytes exceeds the duplex staging cap: it runs zero-copy", need_out);
-        if (int rc = fit_stage(e->dx_stage_out[par], e->dx_stage_out_bytes[par], need_out)) return rc;
+        if (int rc = fit_stage(e->dx_stage_out[par], e->dx_stage_out_bytes[par], need_out, e->dx_stage_out_idle[par])) return rc;
     }
     struct HostOutScope {                // with the results leaving by DMA the kernels see device memory on both sides
         fe_engine* e; bool was;

@@ -2190,7 +2190,16 @@ bool choose_walk(const FilterDev& f, int njobs, int max_blocks, int np, WalkShap
 template <int KR, int D, int LPB, int NP = 1>
 void launch_walk(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, hipStream_t st) {
     dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
-    hipLaunchKernelGGL((mac_walk_kernel<KR, D, true, 6, LPB, NP>), grid, block, 0, st, jr, f, Y, w.tiles, w.tile_len);
+    // PIN: the window loads issued by inline asm at their step, awaited by hand-counted s_waitcnt (tools/check_isa.py
+    // simulates every such loop on the built code object).  `make NO_PIN=1` builds the same walk with compiler-scheduled
+    // loads and the compiler's own waits — slower (the loads sink to their first use: K2 0.30 -> 0.37 ms at 64 blocks)
+    // but correct by construction: the build to fall back on when a toolchain change makes the check fail.
+#ifdef FOLVE_WALK_NO_PIN
+    constexpr bool kPin = false;
+#else
+    constexpr bool kPin = true;
+#endif
+    hipLaunchKernelGGL((mac_walk_kernel<KR, D, kPin, 6, LPB, NP>), grid, block, 0, st, jr, f, Y, w.tiles, w.tile_len);
 }
 }  // namespace
 
