@@ -211,9 +211,11 @@ def test_benchmarked_shape_parity(engine, oracle):
     ys = [torch.zeros(T * P, C, device="cuda") for _ in range(S)]
     streams = [flt.open_stream(T) for _ in range(S)]
     from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS
+    torch.cuda.synchronize()                 # (the engine has its own HIP stream: torch's fills come first)
     BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], lens, FE_DEVICE_PTRS).run()
     x2 = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
     y2 = [torch.zeros(T * P, C, device="cuda") for _ in range(S)]
+    torch.cuda.synchronize()
     BatchPlan(streams, [x.data_ptr() for x in x2], [y.data_ptr() for y in y2], [T * P] * S, FE_DEVICE_PTRS).run()
     hd = dense_taps(paths, size)
     for s in check:
