@@ -1910,10 +1910,12 @@ struct FwdLaunch {
     static hipError_t run(const StreamJob* jobs, int njobs, int max_blocks, const FilterDev& f, bool pairs_ok,
                           const Tuning& tn, hipStream_t st) {
         const JobRef jr = make_job_ref(jobs, tn);
-        // Stereo fast forms, for launches that fill the chip (below that the per-channel kernel's
-        // twice as many, half as long workgroups finish sooner).
+        // Stereo fast forms, for launches that give every CU two workgroups (below that the per-channel kernel's
+        // twice as many, half as long workgroups finish sooner: a lone stream's 256-block call, K1 21.4 -> 19.9 us and
+        // K3 27.2 -> 24.0 us, 384 blocks 28.7 -> 26.8 / 33.2 -> 30.7; from 512 (block, stream) units on the walkers win:
+        // tools/crossover_fft_forms.py).
         const bool fast = tn.fft_form != 1 && f.cin == 2 && pairs_ok && !(tn.fft_form == 4 && (long long)njobs * max_blocks <= 512) &&
-                          (tn.fft_form == 2 || (long long)njobs * max_blocks >= 256);
+                          (tn.fft_form == 2 || (long long)njobs * max_blocks >= (L == 13 ? 512 : 256));
         if (fast) {
             if constexpr (L == 13) {
                 // P = 8192: walk consecutive blocks
@@ -1983,7 +1985,7 @@ struct InvLaunch {
                 return hipGetLastError();
             }
             const bool fast = tn.fft_form != 1 && pairs_ok && (f.cout == 1 || f.cout == 2) &&
-                              (tn.fft_form == 2 || tn.host_io || (long long)njobs * max_blocks >= 256);
+                              (tn.fft_form == 2 || tn.host_io || (long long)njobs * max_blocks >= (f.cout == 2 ? 512 : 256));
             if (fast) {
                 const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);

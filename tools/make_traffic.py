@@ -14,9 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, S, T, K, C = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 summ = json.load(open(os.path.join(ROOT, "profiles", tag + "_summary.json")))
 ROLES = {
-    "T": {"forward": ("forward_walker_kernel", "forward_chpair_kernel", "forward_dual_kernel"),
+    # (a lone stereo stream's call of fewer than 512 blocks takes the per-channel general kernels: the last names)
+    "T": {"forward": ("forward_walker_kernel", "forward_chpair_kernel", "forward_dual_kernel", "forward_kernel"),
           "mac": ("mac_walk_kernel", "mac_slide_kernel"),
-          "inverse": ("inverse_walker_kernel", "inverse_chpair_kernel")},
+          "inverse": ("inverse_walker_kernel", "inverse_chpair_kernel", "inverse_kernel")},
     "1": {"forward": ("forward_kernel",), "mac": ("mac_kernel<1>",), "inverse": ("inverse_kernel",)},
 }
 
