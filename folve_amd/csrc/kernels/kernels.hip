@@ -1915,7 +1915,7 @@ struct FwdLaunch {
         // K3 27.2 -> 24.0 us, 384 blocks 28.7 -> 26.8 / 33.2 -> 30.7; from 512 (block, stream) units on the walkers win:
         // tools/crossover_fft_forms.py).
         const bool fast = tn.fft_form != 1 && f.cin == 2 && pairs_ok && !(tn.fft_form == 4 && (long long)njobs * max_blocks <= 512) &&
-                          (tn.fft_form == 2 || (long long)njobs * max_blocks >= (L == 13 ? 512 : 256));
+                          (tn.fft_form == 2 || (long long)njobs * max_blocks >= (L == 13 && !(tn.host_io && !tn.in_resident) ? 512 : 256));   // (PCM over the bus: whole quads from 256 on, as before)
         if (fast) {
             if constexpr (L == 13) {
                 // P = 8192: walk consecutive blocks
