@@ -420,6 +420,19 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
                       "frac": round(by[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if by.get(k) else None,
                       "frac_of_min_bytes": round(tb[k] * units / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "kernel": (entry.get("kernels") or {}).get(k)}
+    # The same stream in longer calls: a one-stream call is launch-chain bound (three dependent kernel boundaries of ~5.8 us
+    # whatever the call's length), so the run-ahead depth the caller chooses sets how much of the
+    # roof a lone stream sees.  Reported beside the 256-block figure, never instead of it.
+    longer = None
+    if not cfg.get("frames") and T < 1024:
+        try:
+            r4 = measure_config(T=1024, steps=max(20, steps // 3), tune=tune, dev=dev, check=False, **cfg)
+            tb4 = tiled_bytes(P, K, 1024)
+            longer = {"blocks_per_call": 1024, "ms_per_call": round(r4["ms_per_call"], 4), "msamples_per_s": round(r4["msamples_per_s"], 1),
+                      "path_frac_of_min_bytes": round(tb4["total"] * S * C * 1024 / (r4["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "kernels_ms": {k: round(v, 4) for k, v in r4["kernels_ms"].items()}}
+        except Exception as e:  # noqa: BLE001
+            longer = {"error": repr(e)}
     cpu_leg = None
     if cpu:
         try:
@@ -434,7 +447,7 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
     return {"workload": "%s: %s; P=%d, %d blocks per call, PCM resident in HBM" % (name, cfg["what"], P, T),
             "msamples_per_s": round(r["msamples_per_s"], 1), "ms_per_call": round(r["ms_per_call"], 4),
             "realtime_factor": round(r["frames_per_call"] / (r["ms_per_call"] * 1e-3) / cfg["rate"], 0),
-            "cpu": cpu_leg,
+            "cpu": cpu_leg, "longer_calls": longer,
             "blocks_per_call": T, "partitions": K, "populated_partitions": r["populated_partitions"],
             "parity_rms": r["parity_rms"],
             "roofline": {"bound": "hbm", "kernel": {"forward": "K1 forward", "mac": "K2 mac", "inverse": "K3 inverse"}[dominant],
