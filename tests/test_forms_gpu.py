@@ -25,7 +25,7 @@ def _rms(a):
 def tuned(engine):
     """The session engine with every knob back on automatic afterwards."""
     yield engine
-    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0)
+    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0, split=0, duplex_cap_mb=0)
 
 
 def test_xlane_exchange_semantics(engine):
@@ -484,6 +484,40 @@ def test_automatic_walk_shapes_for_one_stream_calls(tuned, oracle):
         c = C - 1
         y64 = oracle.linear_convolution_f64(x[:40 * P], {(c, c): dense_taps(paths, size)[(c, c)]}, C)[:, c]
         assert _rms(y_auto[:40 * P, c] - y64) <= TOL
+
+
+def test_lone_stream_measurement_knobs_keep_the_results(tuned, oracle):
+    """The two forms round 4 measured for a lone stream's long call and did not adopt stay
+    selectable for measurements, so they stay correct: FE_TUNE_SPLIT — the call's blocks as 2 .. 5 time tiles whose
+    K1 -> K2 -> K3 chains alternate between the two launch lanes, tile c's K2 behind tile c - 1's K1 by event — and
+    fft_form = 4, the one-block pair kernels for a stereo stream's whole call.  Two calls each, the second in the automatic
+    form on the state the first left (ring positions, cross-lane ordering): equal to the automatic form within float32
+    rounding, and right."""
+    rng = np.random.default_rng(404)
+    for size, C, T in ((204800, 2, 96), (524288, 8, 64)):
+        paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+        _, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+        P = flt.block_size
+        x1 = rng.uniform(-1, 1, (T * P - 321, C)).astype(np.float32)        # (a short last block: time advances by whole blocks)
+        x2 = rng.uniform(-1, 1, (17 * P, C)).astype(np.float32)
+        tuned.set_tuning(split=1, fft_form=0)
+        st = flt.open_stream(T)
+        ref = [st.process_blocks(x1), st.process_blocks(x2)]
+        knobs = [dict(split=2), dict(split=3), dict(split=5)] + ([dict(split=1, fft_form=4)] if C == 2 else [])
+        for kn in knobs:
+            tuned.set_tuning(split=1, fft_form=0)
+            tuned.set_tuning(**kn)
+            st = flt.open_stream(T)
+            y1 = st.process_blocks(x1)
+            tuned.set_tuning(split=1, fft_form=0)
+            y2 = st.process_blocks(x2)
+            assert _rms(y1 - ref[0]) <= 2e-6 and _rms(y2 - ref[1]) <= 2e-6, (C, kn)
+        c = C - 1
+        pad = (-len(x1)) % P
+        xx = np.concatenate([x1, np.zeros((pad, C), np.float32), x2])
+        y64 = oracle.linear_convolution_f64(xx, {(c, c): dense_taps(paths, size)[(c, c)]}, C)[:, c]
+        assert _rms(ref[0][:, c] - y64[:len(x1)]) <= TOL and _rms(ref[1][:, c] - y64[len(x1) + pad:]) <= TOL
+    tuned.set_tuning(split=0, fft_form=0)
 
 
 @pytest.mark.parametrize("channels,size", [(4, 20000), (8, 20000), (6, 3000), (64, 128)])
