@@ -406,12 +406,13 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
         except Exception:
             entry = {}
     by = entry.get("bytes") or {}
-    # (HIP events around a kernel of a few tens of microseconds read 4 - 8 us long: agreement within 25 % or 10 us)
-    ok = bool(by) and all(abs(kms[k] * 1e6 - (entry.get("avg_ns") or {}).get(k, 0)) <= max(0.25 * (entry.get("avg_ns") or {}).get(k, 1), 10e3)
+    # (HIP events around a kernel of a few tens of microseconds read 4 - 10 us long, more on a box whose clocks have not
+    # settled: agreement within 25 % or 14 us)
+    ok = bool(by) and all(abs(kms[k] * 1e6 - (entry.get("avg_ns") or {}).get(k, 0)) <= max(0.25 * (entry.get("avg_ns") or {}).get(k, 1), 14e3)
                           for k in by)
     note = None
     if by and not ok:
-        note = "in-run kernel times differ from profile %s's by more than 25 %% (and 10 us): its traffic is not used" % entry.get("profile")
+        note = "in-run kernel times differ from profile %s's by more than 25 %% (and 14 us): its traffic is not used" % entry.get("profile")
         by = {}
     path_bytes = sum(by.values()) if len(by) == 3 else None
     kernels = {}
