@@ -121,15 +121,17 @@ fe_engine* DeviceRouter::PickEngine(const std::vector<fe_engine*>* tried) {
         for (fe_engine* t : *tried) if (t == s->engine) return true;
         return false;
     };
-    std::set<const Slot*> gave_up;                   // slots this very call has probed without success
+    std::set<const Slot*> gave_up;                   // slots this very call has probed (or waited for) without success
     for (;;) {
         const double now = Now();
         Slot* best = NULL;
         Slot* due = NULL;                            // a sick slot whose re-probe is due
         Slot* sick = NULL;                           // the sick slot looked at longest ago (last resort)
+        Slot* busy = NULL;                           // a slot another thread is probing right now
         for (auto& sp : slots_) {
             Slot* s = sp.get();
-            if (was_tried(s) || gave_up.count(s) || s->probing) continue;
+            if (was_tried(s) || gave_up.count(s)) continue;
+            if (s->probing) { busy = s; continue; }
             const int st = s->state.load();
             if (st != kHealthy) {
                 if (now - s->looked_at >= reprobe_s_ && (!due || s->looked_at < due->looked_at)) due = s;
@@ -143,8 +145,16 @@ fe_engine* DeviceRouter::PickEngine(const std::vector<fe_engine*>* tried) {
             continue;                                // choose again with what the probe found
         }
         if (!best) {
-            if (!sick) return NULL;
-            if (!ProbeSlot(sick, &lk)) gave_up.insert(sick);
+            if (sick) {
+                if (!ProbeSlot(sick, &lk)) gave_up.insert(sick);
+                continue;
+            }
+            if (!busy) return NULL;
+            // nothing else is left and somebody is asking that GPU right now: its answer is worth a bounded wait (two files
+            // opened at the same moment on a box whose only GPU hiccupped must not fail the second one)
+            probed_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(static_cast<long long>(probe_wait_s_ * 1e6)),
+                               [busy] { return !busy->probing; });
+            if (busy->probing || busy->state.load() != kHealthy) gave_up.insert(busy);
             continue;
         }
         if (!best->engine) {

@@ -403,15 +403,21 @@ int router_scenario(const std::string& dir, const std::vector<std::vector<float>
         EXPECT(p == NULL && err == "Problem parsing " + dir + "/filter-44100.conf", "all GPUs dead: %p '%s'", (void*)p, err.c_str());
         for (int s = 0; s < 8; ++s) EXPECT(R->live_streams(s) == 0, "slot %d keeps %d reservations", s, R->live_streams(s));
     }
-    // ... and one comes back
+    // ... and one comes back — slowly: its probe takes 150 ms, and four files are opened at that moment.  One of them
+    // probes, the others find nothing else left and wait for that answer instead of failing.
     g_dead[4] = 0;
+    g_probe_hangs_ms[4] = 150;
     std::this_thread::sleep_for(std::chrono::milliseconds(350));
     {
-        std::string err;
-        folve::SoundProcessor* p = pool.GetOrCreate(dir, 44100, 2, 16, &err);
-        EXPECT(p != NULL && p->device() == 4, "one GPU back: %p", (void*)p);
-        if (p) { EXPECT(one_file(p, 5u, h) <= 1e-6, "the file on the GPU that came back"); delete p; }
+        std::vector<folve::SoundProcessor*> four;
+        EXPECT(open_many(4, 4, &four) == 0, "an open failed while the only GPU left was being probed");
+        for (folve::SoundProcessor* p : four) {
+            EXPECT(p->device() == 4, "one GPU back: device %d", p->device());
+            EXPECT(one_file(p, 5u, h) <= 1e-6, "the file on the GPU that came back");
+            delete p;
+        }
     }
+    g_probe_hangs_ms[4] = 0;
     printf("{\"router_scenario\": \"%s\", \"failed_checks\": %d}\n", g_fail ? "bad" : "ok", g_fail);
     return g_fail ? 1 : 0;
 }
