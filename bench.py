@@ -860,6 +860,19 @@ def main():
                 multi["what"] = ("one process, %d file threads over %d GPUs through folve::DeviceRouter (streams to the least-loaded "
                                  "GPU, one combiner and one engine per GPU, no collective), run-ahead 64, threads and rings "
                                  "NUMA-placed next to their GPU" % (nt, ndev))
+            # cfg5's shape on ONE device: eight router slots (eight engines, combiners and copies of the filter) on this GPU,
+            # 512 file threads, 64 per slot — everything of the 8-GPU in-process path except seven more devices and buses.
+            # What it shows is that the sharder, the per-slot combiners and 512 threads cost nothing beside one slot's 64
+            # threads on the same bus; the 8-GPU rate itself needs the hardware (`drop_in_threads_multi_gpu`).
+            cfg5_one = None
+            if ndev == 1:
+                env = dict(os.environ, FOLVE_AMD_DEVICES="0,0,0,0,0,0,0,0")
+                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), "512", "768", "1", "json", "run_ahead=64"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, env=env)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                cfg5_one = json.loads(line[-1]) if line else {"error": "rc %d" % r.returncode}
+                cfg5_one["what"] = ("cfg5's shape on one device: 512 file threads over 8 router slots (FOLVE_AMD_DEVICES=0,0,0,0,0,0,0,0), "
+                                    "64 streams per slot, run-ahead 64; one GPU and one bus carry all eight slots")
             # every run against the bus: bytes each way per second, and as a fraction of what `end_to_end` moved in this run
             e2e_gbs = (end_to_end or {}).get("pcie_GBs_each_way")
             for r_ in runs:
@@ -872,7 +885,7 @@ def main():
                                "sf_readf_float / sf_writef_float-shaped callbacks that copy every block in and out, K = %d; "
                                "run_ahead = blocks a processor reads ahead of its reader (1 = the reference's one block per "
                                "Process() call); child process, tools/dropin/dropin_threads.cpp" % K,
-                       "usable_cpus": usable_cpus()[0], "runs": runs, "multi_gpu": multi}
+                       "usable_cpus": usable_cpus()[0], "runs": runs, "multi_gpu": multi, "cfg5_shape_one_device": cfg5_one}
         except Exception as e:  # noqa: BLE001
             drop_in = {"error": repr(e)}
 

@@ -71,7 +71,7 @@ bool DeviceRouter::ProbeSlot(Slot* s, std::unique_lock<std::mutex>* lk) {
     probes_in_flight_++;
     const int slot_index = static_cast<int>(std::find_if(slots_.begin(), slots_.end(),
                                                          [&](const std::unique_ptr<Slot>& p) { return p.get() == s; }) - slots_.begin());
-    std::thread([this, s, slot_index] {
+    auto look = [this, s, slot_index] {
         fe_engine* e;
         { std::lock_guard<std::mutex> g(mu_); e = s->engine; }
         bool ok = true;
@@ -100,7 +100,15 @@ bool DeviceRouter::ProbeSlot(Slot* s, std::unique_lock<std::mutex>* lk) {
             probes_in_flight_--;
         }
         probed_.notify_all();
-    }).detach();
+    };
+    try {
+        std::thread(look).detach();
+    } catch (...) {
+        // no thread to be had: look from here (unbounded, but better than leaving the slot marked as being probed for good)
+        lk->unlock();
+        look();
+        lk->lock();
+    }
     // (wait_until on the system clock: pthread_cond_timedwait, which ThreadSanitizer knows, unlike the clockwait of wait_for)
     probed_.wait_until(*lk, std::chrono::system_clock::now() + std::chrono::microseconds(static_cast<long long>(probe_wait_s_ * 1e6)),
                        [s] { return !s->probing; });

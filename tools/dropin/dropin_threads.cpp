@@ -190,14 +190,17 @@ int main(int argc, char** argv) {
         gpus += b;
     }
     gpus += "}";
+    std::string slots = "[";                                  // streams per router slot while every file is open (one slot per GPU, or as FOLVE_AMD_DEVICES says)
+    for (int k = 0; k < fh_router_device_count(); ++k) slots += (k ? ", " : "") + std::to_string(fh_router_live_streams(k));
+    slots += "]";
     char rms_txt[32];
     snprintf(rms_txt, sizeof(rms_txt), "%.3g", worst_rms);
     if (json) {
         printf("{\"threads\": %d, \"combiner\": %s, \"run_ahead\": %d, \"blocks_per_s\": %.0f, \"msamples_per_s\": %.1f, \"block_latency_us_median\": %.1f, "
                "\"block_latency_us_p99\": %.1f, \"requests\": %lld, \"engine_calls\": %lld, \"largest_batch_blocks\": %lld, \"overlapped_batches\": %lld, "
-               "\"gpus\": %s, \"numa_pin\": %s, \"verified_rms\": %s, \"ok\": %s}\n",
+               "\"gpus\": %s, \"router_slots\": %s, \"numa_pin\": %s, \"verified_rms\": %s, \"ok\": %s}\n",
                nthreads, batching ? "true" : "false", run_ahead, blocks / dt, blocks * P * cout / dt / 1e6, all[all.size() / 2], all[all.size() * 99 / 100],
-               r1 - r0, b1 - b0, l1, o1 - o0, gpus.c_str(), pin ? "true" : "false", verify ? rms_txt : "null", ok ? "true" : "false");
+               r1 - r0, b1 - b0, l1, o1 - o0, gpus.c_str(), slots.c_str(), pin ? "true" : "false", verify ? rms_txt : "null", ok ? "true" : "false");
         for (auto* p : procs) fh_processor_destroy(p);
         return ok ? 0 : 1;
     }
