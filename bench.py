@@ -867,12 +867,16 @@ def main():
             cfg5_one = None
             if ndev == 1:
                 env = dict(os.environ, FOLVE_AMD_DEVICES="0,0,0,0,0,0,0,0")
-                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), "512", "768", "1", "json", "run_ahead=64"],
+                r = subprocess.run([exe, os.path.join(d, "filter-44100.conf"), "512", "2048", "1", "json", "run_ahead=64"],
                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, env=env)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 cfg5_one = json.loads(line[-1]) if line else {"error": "rc %d" % r.returncode}
                 cfg5_one["what"] = ("cfg5's shape on one device: 512 file threads over 8 router slots (FOLVE_AMD_DEVICES=0,0,0,0,0,0,0,0), "
-                                    "64 streams per slot, run-ahead 64; one GPU and one bus carry all eight slots")
+                                    "64 streams per slot, run-ahead 64; one GPU and one bus carry all eight slots.  NOT a stand-in for the "
+                                    "8-GPU rate: engines that share a device share its copy engines and its bus (two slots x 64 threads on "
+                                    "one device: 266 k blocks/s against 562 k for one slot x 64), and 512 threads share this box's CPU quota; "
+                                    "it shows that the sharder places 64 streams on every slot and that all eight engines, combiners and "
+                                    "pipelines run at once")
             # every run against the bus: bytes each way per second, and as a fraction of what `end_to_end` moved in this run
             e2e_gbs = (end_to_end or {}).get("pcie_GBs_each_way")
             for r_ in runs:
