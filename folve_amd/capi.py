@@ -91,6 +91,7 @@ ENGINE_SYMBOLS = [
     ("fe_engine_get_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
     ("fe_engine_reset_profile", _i, [_vp]),
     ("fe_engine_hbm_rates", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
+    ("fe_engine_hbm_rates2", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
 ]
 
 
@@ -182,6 +183,12 @@ class Engine:
         g = (C.c_double * 3)()
         _chk(lib().fe_engine_hbm_rates(self.h, nbytes, reps, g), "fe_engine_hbm_rates")
         return {"read": float(g[0]), "write": float(g[1]), "copy": float(g[2])}
+
+    def hbm_rates2(self, nbytes=1 << 31, reps=20):
+        """hbm_rates plus "write_regions" / "copy_regions": every workgroup storing into its own contiguous region."""
+        g = (C.c_double * 5)()
+        _chk(lib().fe_engine_hbm_rates2(self.h, nbytes, reps, g), "fe_engine_hbm_rates2")
+        return {"read": float(g[0]), "write": float(g[1]), "copy": float(g[2]), "write_regions": float(g[3]), "copy_regions": float(g[4])}
 
     def close(self):
         if self.h:

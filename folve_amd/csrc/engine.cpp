@@ -1759,7 +1759,10 @@ int fe_engine_get_profile(fe_engine* e, long long launches[FE_K_COUNT], double m
     return FE_OK;
 }
 
-int fe_engine_hbm_rates(fe_engine* e, size_t bytes, int reps, double gbs[3]) {
+static int hbm_rates_n(fe_engine* e, size_t bytes, int reps, double* gbs, int modes);
+int fe_engine_hbm_rates(fe_engine* e, size_t bytes, int reps, double gbs[3]) { return hbm_rates_n(e, bytes, reps, gbs, 3); }
+int fe_engine_hbm_rates2(fe_engine* e, size_t bytes, int reps, double gbs[5]) { return hbm_rates_n(e, bytes, reps, gbs, 5); }
+static int hbm_rates_n(fe_engine* e, size_t bytes, int reps, double* gbs, int modes) {
     if (!e || !gbs || reps < 1 || bytes < ((size_t)1 << 20)) return fail(FE_ERR_PARAM, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->device));
@@ -1773,7 +1776,7 @@ int fe_engine_hbm_rates(fe_engine* e, size_t bytes, int reps, double gbs[3]) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     hipError_t rc = hipEventCreate(&e1);
-    for (int mode = 0; mode < 3 && rc == hipSuccess; ++mode) {
+    for (int mode = 0; mode < modes && rc == hipSuccess; ++mode) {
         for (int w = 0; w < 2 && rc == hipSuccess; ++w) rc = fk::launch_hbm_probe(mode, a.p, b.p, bytes, e->stream);
         if (rc == hipSuccess) rc = hipEventRecord(e0, e->stream);
         for (int r = 0; r < reps && rc == hipSuccess; ++r) rc = fk::launch_hbm_probe(mode, a.p, b.p, bytes, e->stream);
@@ -1781,7 +1784,7 @@ int fe_engine_hbm_rates(fe_engine* e, size_t bytes, int reps, double gbs[3]) {
         if (rc == hipSuccess) rc = hipEventSynchronize(e1);
         float ms = 0.f;
         if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, e0, e1);
-        if (rc == hipSuccess) gbs[mode] = (mode == 2 ? 2.0 : 1.0) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+        if (rc == hipSuccess) gbs[mode] = (mode == 2 || mode == 4 ? 2.0 : 1.0) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
     }
     (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

@@ -2054,6 +2054,20 @@ __global__ __launch_bounds__(256) void hbm_write_kernel(v4f* __restrict__ b, siz
 __global__ __launch_bounds__(256) void hbm_copy_kernel(const v4f* __restrict__ a, v4f* __restrict__ b, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
 }
+// The same stores, every workgroup into its OWN contiguous region (what K1, K3 and a tiled K2 do: a workgroup walks its
+// rows) instead of one front of consecutive kilobytes moving through the buffer: 5.6 - 6.1 TB/s against 4.0 - 5.1
+// (tools/micro/write_rate.hip; reads do not care: 6.0 - 6.4 TB/s either way).
+__global__ __launch_bounds__(256) void hbm_write_regions_kernel(v4f* __restrict__ b, size_t n) {
+    const size_t per = n / gridDim.x;
+    v4f* __restrict__ p = b + (size_t)blockIdx.x * per;
+    for (size_t i = threadIdx.x; i < per; i += 256) p[i] = v4f{1.f, 2.f, 3.f, 4.f};
+}
+__global__ __launch_bounds__(256) void hbm_copy_regions_kernel(const v4f* __restrict__ a, v4f* __restrict__ b, size_t n) {
+    const size_t per = n / gridDim.x;
+    const v4f* __restrict__ pa = a + (size_t)blockIdx.x * per;
+    v4f* __restrict__ pb = b + (size_t)blockIdx.x * per;
+    for (size_t i = threadIdx.x; i < per; i += 256) pb[i] = pa[i];
+}
 }  // namespace
 
 hipError_t launch_hbm_probe(int mode, const void* a, void* b, size_t bytes, hipStream_t st) {
@@ -2061,7 +2075,9 @@ hipError_t launch_hbm_probe(int mode, const void* a, void* b, size_t bytes, hipS
     dim3 grid(2048), block(256);                              // 8 workgroups per CU, grid-stride
     if (mode == 0) hipLaunchKernelGGL(hbm_read_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);
     else if (mode == 1) hipLaunchKernelGGL(hbm_write_kernel, grid, block, 0, st, (v4f*)b, n);
-    else hipLaunchKernelGGL(hbm_copy_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);
+    else if (mode == 2) hipLaunchKernelGGL(hbm_copy_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);
+    else if (mode == 3) hipLaunchKernelGGL(hbm_write_regions_kernel, dim3(8192), block, 0, st, (v4f*)b, n);
+    else hipLaunchKernelGGL(hbm_copy_regions_kernel, dim3(8192), block, 0, st, (const v4f*)a, (v4f*)b, n);
     return hipGetLastError();
 }
 

@@ -216,6 +216,11 @@ int fe_engine_reset_profile(fe_engine *e);
  * passes, HIP events): gbs[0] reading, gbs[1] writing, gbs[2] copying (bytes read + written), in GB/s.
  * bench.py prints them beside the nominal 8 TB/s its roofline fraction divides by. */
 int fe_engine_hbm_rates(fe_engine *e, size_t bytes, int reps, double gbs[3]);
+/* The same plus two rates with every workgroup writing its OWN contiguous region of the buffer instead of one front of
+ * consecutive kilobytes moving through it — the pattern of the engine's kernels, whose workgroups walk their rows:
+ * gbs[3] writing, gbs[4] copying (bytes read + written).  On MI355X stores care (5.6 - 6.1 TB/s against 4.0 - 5.1), loads do
+ * not (tools/micro/write_rate.hip). */
+int fe_engine_hbm_rates2(fe_engine *e, size_t bytes, int reps, double gbs[5]);
 
 #ifdef __cplusplus
 }

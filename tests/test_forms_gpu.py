@@ -186,6 +186,9 @@ def test_hbm_rate_hook(engine):
     r = engine.hbm_rates(256 << 20, 5)
     assert set(r) == {"read", "write", "copy"}
     assert all(500.0 < v < 20000.0 for v in r.values()), r
+    r2 = engine.hbm_rates2(256 << 20, 5)
+    assert set(r2) == {"read", "write", "copy", "write_regions", "copy_regions"}
+    assert all(500.0 < v < 20000.0 for v in r2.values()), r2
     with pytest.raises(Exception):
         engine.hbm_rates(1024, 1)                          # below the 1 MiB floor: FE_ERR_PARAM
 
