@@ -460,15 +460,16 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
                 if (any) enqueued[side] = true;
             }
         }
-    } else
-    for (Group& g : groups) {
-        const int side = two && load[1] < load[0] ? 1 : 0;      // 0: `lane`, 1: the other one
-        load[side] += g.work;
-        bool any = true;
-        while (any) {
-            int rc = launch_round(e, g.f, g.items, &any, side ? other : lane, after_k1);
-            if (rc) { drain(); return rc; }
-            enqueued[side] = true;
+    } else {
+        for (Group& g : groups) {
+            const int side = two && load[1] < load[0] ? 1 : 0;  // 0: `lane`, 1: the other one
+            load[side] += g.work;
+            bool any = true;
+            while (any) {
+                int rc = launch_round(e, g.f, g.items, &any, side ? other : lane, after_k1);
+                if (rc) { drain(); return rc; }
+                enqueued[side] = true;
+            }
         }
     }
     if (two && enqueued[1]) {
