@@ -2217,7 +2217,14 @@ void launch_walk(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, con
 #else
     constexpr bool kPin = true;
 #endif
-    hipLaunchKernelGGL((mac_walk_kernel<KR, D, kPin, 6, LPB, NP>), grid, block, 0, st, jr, f, Y, w.tiles, w.tile_len);
+    // accumulators per lane: four (the real- and imaginary-part products of every second partition).  Six was round 2's
+    // number (the hazard padding between dependent inline-asm FMAs); with the wait a step ahead of the use four is enough
+    // and saves two packed adds per step: K2 of cfg3's diagonal batch 0.975 -> 0.963 ms, of its 2 x 2 matrix 1.805 -> 1.752,
+    // of cfg4 120.7 -> 118.0 us (A/B/A, `-DFOLVE_WALK_NACC=n` variants; two: the same as four, eight: 2 % slower).
+#ifndef FOLVE_WALK_NACC
+#define FOLVE_WALK_NACC 4
+#endif
+    hipLaunchKernelGGL((mac_walk_kernel<KR, D, kPin, FOLVE_WALK_NACC, LPB, NP>), grid, block, 0, st, jr, f, Y, w.tiles, w.tile_len);
 }
 }  // namespace
 
