@@ -467,6 +467,72 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
                          "kernels": kernels}}
 
 
+def cpu_baseline_leg(args, P, C, size):
+    """The CPU path timed on this box's host cores, on a bounded sample of the benchmarked workload (rank 0 only; at
+    N > 1 after the process group is gone, so that no rank waits in an RCCL barrier while the CPU works)."""
+    from oracle import oracle as O      # CPU restatement: the baseline being reported, not the product
+    native = O.native_bench_lib() is not None
+    cores, host_cpus, cores_why = usable_cpus()
+    zita = bool(ctypes.util.find_library("zita-convolver")) and any(
+        os.path.exists(os.path.join(d, "zita-convolver.h")) for d in ("/usr/include", "/usr/local/include"))
+
+    def timed(fn, budget):
+        """(all-core rate, sample text, one-core rate, sample text) of one CPU engine, sized to `budget` seconds."""
+        # a short probe runs ~2.5x faster per block than the steady state (cold DRAM working set of
+        # 8 MB per stream builds up), so size the sample from a 16-block probe
+        tprobe = fn(cores, 16, cores) / 16.0                                  # seconds per block round
+        nblocks = int(max(8, min(65536, budget / max(tprobe * 1.5, 1e-4))))
+        tall = fn(cores, nblocks, cores)
+        tp1 = fn(1, 64, 1) / 64.0                                             # one stream alone is cache-resident: its own probe
+        nb1 = int(max(64, min(65536, 0.4 * budget / max(tp1, 1e-6))))
+        t1 = fn(1, nb1, 1)
+        return (cores * nblocks * P * C / tall / 1e6,
+                "%d streams x %d blocks x %d ch, %d taps, one convolver per stream, %d threads, %.1f s" % (cores, nblocks, C, size, cores, tall),
+                nb1 * P * C / t1 / 1e6,
+                "1 stream x %d blocks, 1 thread, %.1f s (one stream's 8 MB of state stays in cache)" % (nb1, t1))
+
+    # the vectorised stand-in (oracle/fastcpu.c: split-complex radix-4 Stockham FFT, FMA multiply-accumulate) is the
+    # figure to compare with; the scalar parity oracle is timed beside it
+    fv, fs, f1, f1s = timed(lambda ns, nb, nt: O.fast_bench_streams(ns, nb, nt, C, size, 3, native=native), 0.6 * args.cpu_seconds)
+    sv, ss, s1, s1s = timed(lambda ns, nb, nt: O.bench_streams(ns, nb, nt, C, C, size, 3, native=native), 0.4 * args.cpu_seconds)
+    cpu = {"value": round(fv, 2), "unit": "Msamples/s", "cores": cores,
+           "cores_note": "%d threads = the CPUs this process may use (%s); the host has %d" % (cores, cores_why, host_cpus),
+           "kind": "port",
+           "what": "CPU restatement of zita-convolver's algorithm as folve configures it (one level, partition 8192, one engine "
+                   "per open file: /root/reference/zita-fconfig.cc:74-81), vectorised: split-complex radix-4 Stockham real FFT and "
+                   "an FMA multiply-accumulate over structure-of-arrays spectra (oracle/fastcpu.c).  zita-convolver / FFTW are "
+                   "unavailable offline: this is a stand-in, not zita.  Its time is the multiply-accumulate streaming K spectra "
+                   "of the stream and of the filter per block (4 MB per channel and block) through the cache hierarchy.",
+           "build": "-O3 -march=native on this box" if native else "-O3 -march=x86-64-v3 (prebuilt)",
+           "sample": fs,
+           "one_core": {"value": round(f1, 2), "unit": "Msamples/s", "cores": 1, "sample": f1s},
+           "scalar_oracle": {"value": round(sv, 2), "unit": "Msamples/s", "cores": cores, "sample": ss,
+                             "one_core": {"value": round(s1, 2), "sample": s1s},
+                             "what": "the parity oracle itself (oracle_convproc.c + oracle_fft.c: scalar radix-2 FFT, written to be "
+                                     "read): a pessimistic figure, kept for continuity with rounds 1 - 2"},
+           "zita_convolver_on_this_box": zita}
+    return cpu
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks ourselves, one per GPU, as a CHILD
+    process (`python -m torch.distributed.run`, rendezvous on 127.0.0.1 at a free port) and hand back its exit code.  This
+    process has imported neither torch nor the engine at this point, so nothing here has touched the GPU; the child's
+    stdout is ours, so rank 0's JSON line comes out unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks (torch.distributed.run, port %d)\n" % (n, n, port))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,6 +552,8 @@ def main():
                     help="run only this configuration's loop and print its `configs` entry (what tools/profile.sh profiles)")
     ap.add_argument("--config-blocks", type=int, default=256, help="blocks per call of the cfg2 / cfg4 legs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if args.only_config:
         import torch  # noqa: F401
         tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))} if args.tune else None
@@ -507,10 +575,18 @@ def main():
     backend = os.environ.get("FOLVE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # FOLVE_BENCH_FORCE_DIST=1: a process group even at world size 1, so that the RCCL branch below (init, barrier, the
+    # reductions of sharding.aggregate_throughput beside the engine's own HIP streams) runs on a one-GPU box
+    force_dist = world == 1 and os.environ.get("FOLVE_BENCH_FORCE_DIST", "") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
@@ -923,50 +999,6 @@ def main():
         except Exception as e:  # noqa: BLE001
             mixed_filters = {"error": repr(e)}
 
-    cpu = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        from oracle import oracle as O      # CPU restatement: the baseline being reported, not the product
-        native = O.native_bench_lib() is not None
-        cores, host_cpus, cores_why = usable_cpus()
-        zita = bool(ctypes.util.find_library("zita-convolver")) and any(
-            os.path.exists(os.path.join(d, "zita-convolver.h")) for d in ("/usr/include", "/usr/local/include"))
-
-        def timed(fn, budget):
-            """(all-core rate, sample text, one-core rate, sample text) of one CPU engine, sized to `budget` seconds."""
-            # a short probe runs ~2.5x faster per block than the steady state (cold DRAM working set of
-            # 8 MB per stream builds up), so size the sample from a 16-block probe
-            tprobe = fn(cores, 16, cores) / 16.0                                  # seconds per block round
-            nblocks = int(max(8, min(65536, budget / max(tprobe * 1.5, 1e-4))))
-            tall = fn(cores, nblocks, cores)
-            tp1 = fn(1, 64, 1) / 64.0                                             # one stream alone is cache-resident: its own probe
-            nb1 = int(max(64, min(65536, 0.4 * budget / max(tp1, 1e-6))))
-            t1 = fn(1, nb1, 1)
-            return (cores * nblocks * P * C / tall / 1e6,
-                    "%d streams x %d blocks x %d ch, %d taps, one convolver per stream, %d threads, %.1f s" % (cores, nblocks, C, size, cores, tall),
-                    nb1 * P * C / t1 / 1e6,
-                    "1 stream x %d blocks, 1 thread, %.1f s (one stream's 8 MB of state stays in cache)" % (nb1, t1))
-
-        # the vectorised stand-in (oracle/fastcpu.c: split-complex radix-4 Stockham FFT, FMA multiply-accumulate) is the
-        # figure to compare with; the scalar parity oracle is timed beside it
-        fv, fs, f1, f1s = timed(lambda ns, nb, nt: O.fast_bench_streams(ns, nb, nt, C, size, 3, native=native), 0.6 * args.cpu_seconds)
-        sv, ss, s1, s1s = timed(lambda ns, nb, nt: O.bench_streams(ns, nb, nt, C, C, size, 3, native=native), 0.4 * args.cpu_seconds)
-        cpu = {"value": round(fv, 2), "unit": "Msamples/s", "cores": cores,
-               "cores_note": "%d threads = the CPUs this process may use (%s); the host has %d" % (cores, cores_why, host_cpus),
-               "kind": "port",
-               "what": "CPU restatement of zita-convolver's algorithm as folve configures it (one level, partition 8192, one engine "
-                       "per open file: /root/reference/zita-fconfig.cc:74-81), vectorised: split-complex radix-4 Stockham real FFT and "
-                       "an FMA multiply-accumulate over structure-of-arrays spectra (oracle/fastcpu.c).  zita-convolver / FFTW are "
-                       "unavailable offline: this is a stand-in, not zita.  Its time is the multiply-accumulate streaming K spectra "
-                       "of the stream and of the filter per block (4 MB per channel and block) through the cache hierarchy.",
-               "build": "-O3 -march=native on this box" if native else "-O3 -march=x86-64-v3 (prebuilt)",
-               "sample": fs,
-               "one_core": {"value": round(f1, 2), "unit": "Msamples/s", "cores": 1, "sample": f1s},
-               "scalar_oracle": {"value": round(sv, 2), "unit": "Msamples/s", "cores": cores, "sample": ss,
-                                 "one_core": {"value": round(s1, 2), "sample": s1s},
-                                 "what": "the parity oracle itself (oracle_convproc.c + oracle_fft.c: scalar radix-2 FFT, written to be "
-                                         "read): a pessimistic figure, kept for continuity with rounds 1 - 2"},
-               "zita_convolver_on_this_box": zita}
-
     if rank == 0:
         out = {
             "metric": "Msamples/s convolved (44.1k/2ch, 256k-tap) + realtime-stream count; HBM % of peak",
@@ -991,14 +1023,20 @@ def main():
             "drop_in_threads_multi_gpu": (drop_in or {}).get("multi_gpu") if isinstance(drop_in, dict) else None,
             "configs": configs,
             "mixed_filters": mixed_filters,
-            "cpu_baseline": cpu,
+            "cpu_baseline": None,
         }
         if world > 1:
             out["shards"] = [sharding.shard_streams(S * world, world, r) for r in range(world)]
-        print(json.dumps(out))
+        if dist is not None:
+            out["process_group"] = {"backend": backend, "world_size": dist.get_world_size(), "forced_at_world_size_1": force_dist}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU leg runs when every timed GPU region is over and (N > 1) the other ranks are gone: host cores to itself
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(args, P, C, size)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ def owner_of(stream_index, world):
 
 def aggregate_throughput(units_local, seconds_local, dist=None, device=None):
     """(total units over all ranks, max seconds over ranks, units per second)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():          # (a group of one still reduces: bench.py's FOLVE_BENCH_FORCE_DIST)
         return units_local, seconds_local, units_local / seconds_local
     import torch
     t = torch.tensor([seconds_local], dtype=torch.float64, device=device)

@@ -50,3 +50,29 @@ def test_power_reader_on_a_fake_hwmon_tree(tmp_path):
     s = w.summary()
     assert s["socket_w"] == 1400.0 and s["cap_w"] == 1400.0 and s["sclk_mhz"] == 1690.0
     assert s["sclk_max_mhz"] == 2400 and s["at_power_cap"] is True and s["samples"] >= 3
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 4 --steps 7` outside torch.distributed.run: main() must hand over to a CHILD process running the
+    launcher (never an exec, never after importing the engine), with the same arguments, rendezvous on 127.0.0.1."""
+    import subprocess
+    import sys
+    b = _bench()
+    seen = {}
+
+    def fake_call(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    try:
+        b.main()
+        raise AssertionError("main() went on past the self-launch")
+    except SystemExit as e:
+        assert e.code == 7                                            # the child's exit code is ours
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -78,6 +78,45 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["value"] > 0
 
 
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (what the driver's SCALE step may run): bench.py starts its two
+    ranks as a child process itself, and the N = 2 line carries everything the N = 1 line does — roofline, cpu_baseline
+    (timed by rank 0 after the process group is gone), shards.  Both ranks on device 0 over gloo: a one-GPU box."""
+    env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "8",
+           "--blocks", "16", "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["total_streams"] == 16 and out["value"] > 0
+    assert out["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]
+    assert out["process_group"] == {"backend": "gloo", "world_size": 2, "forced_at_world_size_1": False}
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel_ms"] > 0 and out["roofline"]["frac_lower_bound"] > 0
+    cpu = out["cpu_baseline"]
+    assert cpu and cpu["value"] > 0 and cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["sample"]
+    assert out["parity_rms"] <= 1e-5
+
+
+def test_bench_rccl_branch_runs_on_one_gpu():
+    """The RCCL branch of bench.py — init_process_group("nccl", device_id), the barriers around the timed region and the
+    reductions of sharding.aggregate_throughput, beside the engine's private HIP streams — behind FOLVE_BENCH_FORCE_DIST=1
+    at world size 1: everything of the N > 1 launch that one GPU can run."""
+    env = dict(os.environ, FOLVE_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FOLVE_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["process_group"] == {"backend": "nccl", "world_size": 1, "forced_at_world_size_1": True}
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_rms"] <= 1e-5
+
+
 def test_harness_over_two_router_slots_with_numa_placement(tmp_path):
     """bench.py's drop_in_threads_multi_gpu leg on a one-GPU box: the C++ harness with two router slots (both device 0),
     run-ahead on, NUMA placement on (a no-op where sysfs says nothing): the streams split evenly, both engines work."""
