@@ -158,6 +158,33 @@ class PowerWatch:
                 "source": "amdgpu hwmon (power1_input, freq1_input), device by " + ("PCI address" if self.by_address else "highest power")}
 
 
+def norm_kernel(name):
+    """'mac_walk_kernel<33, 7, true, 4, 1, 1> grid=1048576' (profiles/traffic.json) or the engine's own spelling
+    (fe_engine_last_kernels) -> 'mac_walk_kernel<33,7,true,4,1,1>'."""
+    return (name or "").split(" grid=")[0].replace(" ", "")
+
+
+def profile_applies(entry, launched, kms, rel, floor_us, roles=None):
+    """Is profiles/traffic.json's `entry` a profile of THIS run's launches?  Its kernels must be the ones the engine
+    launched — by NAME (the instantiation, as rocprofv3 and fe_engine_last_kernels both spell it) — and this run's kernel
+    times must agree with the profile's kernel-trace averages within `rel` (or `floor_us`: HIP events around a short launch
+    read a few microseconds long).  Returns (ok, note)."""
+    by = entry.get("bytes") or {}
+    if not by:
+        return False, None
+    for k in (roles or by):
+        prof, ran = norm_kernel((entry.get("kernels") or {}).get(k)), norm_kernel((launched or {}).get(k))
+        if not prof or not ran or prof != ran:
+            return False, ("profile %s is of other kernels (%s: profiled %s, launched %s): its traffic is not used"
+                           % (entry.get("profile"), k, prof or "?", ran or "?"))
+    for k in (roles or by):
+        ns = (entry.get("avg_ns") or {}).get(k, 0)
+        if abs(kms[k] * 1e6 - ns) > max(rel * ns, floor_us * 1e3):
+            return False, ("in-run %s time %.1f us differs from profile %s's %.1f us by more than %.0f %%: its traffic is not used"
+                           % (k, kms[k] * 1e3, entry.get("profile"), ns / 1e3, rel * 100))
+    return True, None
+
+
 def usable_cpus():
     """(cpus this process may run on at once, host cpus, why): the affinity mask cut to the cgroup's CPU quota —
     256 threads inside a 16-CPU quota are 16 cores' worth of work with a throttle on top."""
@@ -278,7 +305,8 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
     prof = eng.get_profile()
     eng.set_profiling(False)
     kms = {k: v["ms"] / max(1, v["launches"]) for k, v in prof.items()}
-    out = {"streams": S, "channels": C, "taps": size, "block": P, "partitions": K, "populated_partitions": flt.path_partitions(0, 0),
+    launched = eng.last_kernels()
+    out = {"kernels_launched": launched, "streams": S, "channels": C, "taps": size, "block": P, "partitions": K, "populated_partitions": flt.path_partitions(0, 0),
            "blocks_per_call": T, "ms_per_call": dt * 1e3, "kernels_ms": kms, "msamples_per_s": S * nfr * C / dt / 1e6,
            "frames_per_call": nfr, "parity_rms": parity}
     for s_ in streams:
@@ -406,21 +434,31 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
         except Exception:
             entry = {}
     by = entry.get("bytes") or {}
+    launched = r["kernels_launched"]
     # (HIP events around a kernel of a few tens of microseconds read 4 - 10 us long, more on a box whose clocks have not
-    # settled: agreement within 25 % or 14 us)
-    ok = bool(by) and all(abs(kms[k] * 1e6 - (entry.get("avg_ns") or {}).get(k, 0)) <= max(0.25 * (entry.get("avg_ns") or {}).get(k, 1), 14e3)
-                          for k in by)
-    note = None
+    # settled: agreement within 25 % or 14 us — and the same kernels, by name)
+    ok, note = profile_applies(entry, launched, kms, 0.25, 14.0)
     if by and not ok:
-        note = "in-run kernel times differ from profile %s's by more than 25 %% (and 14 us): its traffic is not used" % entry.get("profile")
         by = {}
     path_bytes = sum(by.values()) if len(by) == 3 else None
+    # A launch of a few tens of microseconds: the engine's HIP events stand one dependent-launch boundary apart, so an
+    # event-to-event time holds the kernel AND the gap behind it (the three of them can add up to more than the call's wall
+    # time).  Where the committed profile is of these very kernels, such a launch's duration is the profile's kernel-trace
+    # average (`trace_us`), printed beside the event time, and `frac` divides by that.
+    trace = entry.get("avg_ns") or {}
     kernels = {}
     for k in kms:
-        kernels[k] = {"ms": round(kms[k], 4), "traffic": by.get(k),
-                      "frac": round(by[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if by.get(k) else None,
-                      "frac_of_min_bytes": round(tb[k] * units / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      "kernel": (entry.get("kernels") or {}).get(k)}
+        short = by.get(k) and trace.get(k) and kms[k] < 0.05
+        t_ms = trace[k] / 1e6 if short else kms[k]
+        kernels[k] = {"ms": round(t_ms, 4), "event_ms": round(kms[k], 4),
+                      "trace_us": round(trace[k] / 1e3, 2) if (by.get(k) and trace.get(k)) else None,
+                      "time_source": ("rocprofv3 kernel trace of profile %s (a launch this short: the event time includes the launch boundary)" % entry.get("profile"))
+                      if short else "HIP events in this run",
+                      "traffic": by.get(k),
+                      "frac": round(by[k] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if by.get(k) else None,
+                      "frac_of_min_bytes": round(tb[k] * units / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "kernel": launched.get(k), "profiled_kernel": (entry.get("kernels") or {}).get(k)}
+    dominant = max(kernels, key=lambda k: kernels[k]["ms"])
     # The same stream in longer calls: a one-stream call is launch-chain bound (three dependent kernel boundaries of ~5.8 us
     # whatever the call's length), so the run-ahead depth the caller chooses sets how much of the
     # roof a lone stream sees.  Reported beside the 256-block figure, never instead of it.
@@ -450,9 +488,9 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
             "realtime_factor": round(r["frames_per_call"] / (r["ms_per_call"] * 1e-3) / cfg["rate"], 0),
             "cpu": cpu_leg, "longer_calls": longer,
             "blocks_per_call": T, "partitions": K, "populated_partitions": r["populated_partitions"],
-            "parity_rms": r["parity_rms"],
+            "parity_rms": r["parity_rms"], "kernels_launched": launched,
             "roofline": {"bound": "hbm", "kernel": {"forward": "K1 forward", "mac": "K2 mac", "inverse": "K3 inverse"}[dominant],
-                         "achieved": round(by[dominant] / (kms[dominant] * 1e-3) / 1e9, 1) if by.get(dominant) else None,
+                         "achieved": round(by[dominant] / (kernels[dominant]["ms"] * 1e-3) / 1e9, 1) if by.get(dominant) else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dominant]["frac"], "traffic": by.get(dominant),
                          "traffic_source": entry.get("profile"), "traffic_note": note,
@@ -725,16 +763,15 @@ def main():
         except Exception:
             tj = {}
     entry = tj.get(shape_key) or {}
+    launched = eng.last_kernels()
     traffic = (entry.get("bytes") or {}).get(dominant)
-    prof_ns = (entry.get("avg_ns") or {}).get(dominant)
     traffic_note = None
-    if traffic is not None and prof_ns:
-        dev_pct = abs(kms[dominant] * 1e6 - prof_ns) / prof_ns
-        if dev_pct > 0.15:
-            traffic_note = ("in-run %s time %.1f us differs from profile %s's %.1f us by %.0f %%: traffic not used"
-                            % (dominant, kms[dominant] * 1e3, entry.get("profile"), prof_ns / 1e3, dev_pct * 100))
-            sys.stderr.write("bench.py: WARNING " + traffic_note + "\n")
+    if traffic is not None:
+        ok, traffic_note = profile_applies(entry, launched, kms, 0.15, 0.0, roles=[dominant])
+        if not ok:
+            sys.stderr.write("bench.py: WARNING " + str(traffic_note) + "\n")
             traffic = None
+    applies = {k: profile_applies(entry, launched, kms, 0.15, 0.0, roles=[k])[0] for k in kms}   # per kernel: same name, same time
     achieved = (traffic / (kms[dominant] * 1e-3) / 1e9) if traffic else None
     frac_alg = ab[dominant] * units_per_launch / (kms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS
     roofline = {"bound": "hbm", "kernel": {"forward": "K1 forward", "mac": "K2 mac", "inverse": "K3 inverse"}[dominant],
@@ -742,6 +779,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 "traffic": traffic, "traffic_source": entry.get("profile"), "traffic_note": traffic_note or entry.get("note"),
                 "kernel_ms": round(kms[dominant], 4), "kernels_ms": {k: round(v, 4) for k, v in kms.items()},
+                "kernels_launched": launched, "kernel_name": launched.get(dominant),
+                "profiled_kernel": (entry.get("kernels") or {}).get(dominant),
                 "min_bytes_per_launch": int(tb[dominant] * units_per_launch),
                 "frac_of_min_bytes": round(tb[dominant] * units_per_launch / (kms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 # never "no roofline": when the committed PMC traffic does not apply to this run (`frac` null, the reason in
@@ -753,10 +792,10 @@ def main():
                 "frac_alg": {"applicable": T == 1, "value": round(frac_alg, 4),
                              "why": "SURVEY.md 8(d)'s streaming formula re-reads K spectra per output block; a "
                                     "run-ahead call re-uses them on chip, so this figure is not a roofline fraction"},
-                "all_kernels": {k: {"ms": round(kms[k], 4),
-                                    "traffic": (entry.get("bytes") or {}).get(k) if traffic is not None else None,
+                "all_kernels": {k: {"ms": round(kms[k], 4), "kernel": launched.get(k),
+                                    "traffic": (entry.get("bytes") or {}).get(k) if applies[k] else None,
                                     "frac": round((entry.get("bytes") or {}).get(k, 0) / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                    if traffic is not None and (entry.get("bytes") or {}).get(k) else None,
+                                    if applies[k] and (entry.get("bytes") or {}).get(k) else None,
                                     "frac_of_min_bytes": round(tb[k] * units_per_launch / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                                 for k in kms},
                 "path": {"min_bytes_per_block_channel": int(tb["total"]),
@@ -774,7 +813,7 @@ def main():
         wrate = max(rates["write"], rates["write_regions"])
         model = {}
         for k in kms:
-            if traffic is not None and rd.get(k) and wr.get(k):
+            if applies[k] and rd.get(k) and wr.get(k):
                 t_model = rd[k] / (rates["read"] * 1e9) + wr[k] / (wrate * 1e9)
                 # ... and against the rate of a plain kernel that reads AND writes (a copy, every workgroup its own region):
                 # mixed traffic pays for the turn-arounds of the DRAM bus, which the two separate rates do not show
@@ -823,10 +862,13 @@ def main():
         k1ms = {k: v["ms"] / max(1, v["launches"]) for k, v in p1.items()}
         mac1_gbs = ab["mac"] * S * C / (k1ms["mac"] * 1e-3) / 1e9
         e1 = tj.get("S%d_T1_K%d_C%d" % (S, K, C)) or {}
+        launched1 = eng.last_kernels()
+        ok1, note1 = profile_applies(e1, launched1, k1ms, 0.25, 5.0, roles=["mac"])
         streaming = {"bound": "hbm", "kernel": "K2 mac (one block per call)", "blocks_per_call": 1,
                      "achieved": round(mac1_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(mac1_gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": int(ab["mac"] * S * C),
-                     "traffic": (e1.get("bytes") or {}).get("mac"), "traffic_source": e1.get("profile"),
+                     "traffic": (e1.get("bytes") or {}).get("mac") if ok1 else None, "traffic_source": e1.get("profile"), "traffic_note": note1,
+                     "kernels_launched": launched1,
                      "kernel_ms": round(k1ms["mac"], 4), "kernels_ms": {k: round(v, 4) for k, v in k1ms.items()},
                      "ms_per_step": round(d1 * 1e3, 4), "msamples_per_s": round(S * P * C / d1 / 1e6, 1),
                      "path_frac": round(ab["total"] * S * C / d1 / 1e9 / HBM_PEAK_GBS, 4)}

@@ -13,10 +13,11 @@ FE_HOST_PTRS, FE_DEVICE_PTRS, FE_ASYNC = 0, 1, 2
 FE_K_FORWARD, FE_K_MAC, FE_K_INVERSE, FE_K_COUNT = 0, 1, 2, 3
 FE_TUNE_FWD_RUN, FE_TUNE_INV_RUN, FE_TUNE_MAC_FORM, FE_TUNE_FFT_FORM, FE_TUNE_FAIL_NEXT, FE_TUNE_LANES = 0, 1, 2, 3, 4, 5
 FE_TUNE_WALK_LPB, FE_TUNE_WALK_TILES, FE_TUNE_DUPLEX_OUT, FE_TUNE_DUPLEX_CHUNK_MB, FE_TUNE_DUPLEX_MIN_MB = 6, 7, 8, 9, 10
-FE_TUNE_SPLIT, FE_TUNE_DUPLEX_CAP_MB = 11, 12
+FE_TUNE_SPLIT, FE_TUNE_DUPLEX_CAP_MB, FE_TUNE_WALK_FMA = 11, 12, 13
 TUNE_KNOBS = {"fwd_run": FE_TUNE_FWD_RUN, "inv_run": FE_TUNE_INV_RUN, "mac_form": FE_TUNE_MAC_FORM,
               "fft_form": FE_TUNE_FFT_FORM, "fail_next": FE_TUNE_FAIL_NEXT, "lanes": FE_TUNE_LANES,
-              "walk_lpb": FE_TUNE_WALK_LPB, "walk_tiles": FE_TUNE_WALK_TILES, "duplex_out": FE_TUNE_DUPLEX_OUT, "duplex_chunk_mb": FE_TUNE_DUPLEX_CHUNK_MB, "duplex_min_mb": FE_TUNE_DUPLEX_MIN_MB, "split": FE_TUNE_SPLIT, "duplex_cap_mb": FE_TUNE_DUPLEX_CAP_MB}
+              "walk_lpb": FE_TUNE_WALK_LPB, "walk_tiles": FE_TUNE_WALK_TILES, "duplex_out": FE_TUNE_DUPLEX_OUT, "duplex_chunk_mb": FE_TUNE_DUPLEX_CHUNK_MB, "duplex_min_mb": FE_TUNE_DUPLEX_MIN_MB, "split": FE_TUNE_SPLIT, "duplex_cap_mb": FE_TUNE_DUPLEX_CAP_MB,
+              "walk_fma": FE_TUNE_WALK_FMA}
 KERNEL_NAMES = ("forward", "mac", "inverse")
 
 
@@ -90,6 +91,7 @@ ENGINE_SYMBOLS = [
     ("fe_engine_set_profiling", _i, [_vp, _i]),
     ("fe_engine_get_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
     ("fe_engine_reset_profile", _i, [_vp]),
+    ("fe_engine_last_kernels", _i, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("fe_engine_hbm_rates", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
     ("fe_engine_hbm_rates2", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
 ]
@@ -177,6 +179,12 @@ class Engine:
         ms = (C.c_double * FE_K_COUNT)()
         _chk(lib().fe_engine_get_profile(self.h, n, ms), "fe_engine_get_profile")
         return {KERNEL_NAMES[k]: {"launches": int(n[k]), "ms": float(ms[k])} for k in range(FE_K_COUNT)}
+
+    def last_kernels(self):
+        """{"forward", "mac", "inverse"}: the kernels of this engine's most recent launch round, as rocprofv3 names them."""
+        bufs = [C.create_string_buffer(96) for _ in range(FE_K_COUNT)]
+        _chk(lib().fe_engine_last_kernels(self.h, bufs[0], bufs[1], bufs[2], 96), "fe_engine_last_kernels")
+        return {KERNEL_NAMES[k]: bufs[k].value.decode() for k in range(FE_K_COUNT)}
 
     def hbm_rates(self, nbytes=1 << 31, reps=20):
         """GB/s this GPU's HBM gives plain streaming kernels: {"read", "write", "copy"} (copy counts both ways)."""

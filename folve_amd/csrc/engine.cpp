@@ -131,7 +131,7 @@ struct fe_engine {
     hipEvent_t dx_ev[16] = {};               // run_duplex: "K1 of chunk c has finished"
     // profiling
     hipEvent_t split_ev[4] = {};         // a lone stream's time tiles on two lanes: "K1 of tile c has finished"
-    int split_tiles = 0;                 // FE_TUNE_SPLIT: 0 automatic, 1 never, 2 .. 8 time tiles for a lone stream's long call
+    int split_tiles = 0;                 // FE_TUNE_SPLIT: 0 / 1 never, 2 .. 8 time tiles for a lone stream's long call (one launch round only)
     int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none, < 0: every round)
     int sync_in_flight = 0;              // synchronous zero-copy calls waiting (lock released) on lane 0
     bool tuning_single_lane = false;     // FE_TUNE_LANES = 1: every submitted batch on lane 0 (measurements)
@@ -139,6 +139,7 @@ struct fe_engine {
     hipEvent_t pev[4] = {};
     long long prof_launches[FE_K_COUNT] = {};
     double prof_ms[FE_K_COUNT] = {};
+    fk::LaunchNames last_names = {};     // the kernels of the most recent launch round (fe_engine_last_kernels)
 };
 
 struct fe_ticket {                  // a submitted batch whose outputs are not yet known to be in the caller's buffers
@@ -340,6 +341,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     tn.max_ring = max_ring;
     if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
     tn.one_job = nj == 1 ? e->jobs_host[slot] : nullptr;
+    tn.names = &e->last_names;
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (after_k1) HIP_TRY(hipEventRecord(after_k1, st));
@@ -422,6 +424,10 @@ int run_groups(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
         // (automatic: never — measured on MI355X, cfg2 62 -> 88 us per 256-block call with two tiles, +14 .. 27 us per further
         // tile: a cross-lane event wait costs more than the gap it hides; the knob stays for measurements)
         if (split < 2) split = 0;
+        // (a span longer than the stream's run-ahead depth takes several launch rounds: the first tile of a later round would
+        // read history spectra that the previous round's last tile wrote on the OTHER lane with nothing ordering the two, and
+        // its K1 could wrap the ring into slots a K2 over there still reads — such a call is not split)
+        if (it.left > (long long)it.s->max_blocks * P) split = 0;
     }
     if (split) two = true;
     if (two) {
@@ -1682,6 +1688,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             if (value < 0 || value > 64) return fail(FE_ERR_PARAM, "time tiles must be 0 .. 64");
             e->tuning.walk_tiles = value;
             return FE_OK;
+        case FE_TUNE_WALK_FMA:
+            if (value != 0 && value != 3 && value != 4) return fail(FE_ERR_PARAM, "walk FMA form must be 0, 3 or 4");
+            e->tuning.walk_fma = value;
+            return FE_OK;
         case FE_TUNE_DUPLEX_OUT:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "duplex out must be 0, 1 or 2");
             e->duplex_out = value;
@@ -1747,6 +1757,15 @@ int fe_engine_set_profiling(fe_engine* e, int on) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
     e->profiling = on != 0;
+    return FE_OK;
+}
+
+int fe_engine_last_kernels(fe_engine* e, char* forward, char* mac, char* inverse, size_t cap) {
+    if (!e || cap == 0) return fail(FE_ERR_PARAM, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    char* dst[FE_K_COUNT] = {forward, mac, inverse};
+    for (int k = 0; k < FE_K_COUNT; ++k)
+        if (dst[k]) snprintf(dst[k], cap, "%s", e->last_names.k[k]);
     return FE_OK;
 }
 

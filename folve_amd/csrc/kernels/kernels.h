@@ -48,6 +48,11 @@ struct FilterDev {
     const float2* twb2;
 };
 
+// Which kernel each of the three launches of a round was (the instantiation as rocprofv3 prints it, without namespace and
+// arguments): filled by the launchers when Tuning::names is set (fe_engine_last_kernels; bench.py matches its committed
+// profiles against these).
+struct LaunchNames { char k[3][96]; };
+
 // Launch-shape choices of one engine (fe_engine_set_tuning; 0 = automatic everywhere).  The
 // automatic choice depends on the batch shape, so tests pin a form to reach it with small batches.
 struct Tuning {
@@ -57,6 +62,8 @@ struct Tuning {
     int fft_form = 0;       // K1/K3: 1 general kernels only, 2 walkers whenever the shape allows (also small launches), 3 no channel-pair walkers (many channels: the one-block-per-workgroup pair kernels)
     int walk_lpb = 0;       // K2 whole-call walk: lanes per bin (1, 2, 4) instead of the automatic choice
     int walk_tiles = 0;     // K2 whole-call walk: time tiles per call
+    int walk_fma = 0;       // K2 whole-call walk: 3 = the three-FMA form (mac_walk3.hip), 4 = the four-FMA form, 0 = by shape
+    LaunchNames* names = nullptr;   // set per call: where the launchers note the kernels they chose
     // set per call: the only descriptor of a one-stream launch, readable by the HOST.  Every kernel then receives it
     // by value among its arguments instead of fetching jobs[0] — a dependent read over the bus when the descriptors
     // sit in page-locked memory (2 us at the start of each of the three latency kernels), an upload in front of K1

@@ -30,6 +30,7 @@
 #include <utility>
 
 #include "fft_core.hpp"
+#include "walk_common.hpp"
 
 namespace fk {
 
@@ -68,19 +69,6 @@ __device__ unsigned int g_stamp_n;
 
 namespace {
 
-// Where a kernel finds its stream descriptors: an array indexed by blockIdx.z, or — a launch of ONE stream — the
-// descriptor itself, among the kernel arguments (Tuning::one_job).  A one-stream call then needs no upload in front of
-// K1 (a copy kernel of 3.6 us behind a 5.8 us dependency gap: 9.5 of the 68 us of a 256-block call of one stereo stream)
-// and the latency kernels no dependent read over the bus.
-struct JobRef {
-    const StreamJob* jobs;
-    StreamJob one;
-};
-__device__ __forceinline__ StreamJob fetch_job(const JobRef& r) { return r.jobs ? r.jobs[blockIdx.z] : r.one; }
-inline JobRef make_job_ref(const StreamJob* jobs, const Tuning& tn) {
-    return tn.one_job ? JobRef{nullptr, *tn.one_job} : JobRef{jobs, StreamJob{}};
-}
-
 // complex multiply-accumulate on two packed bins
 __device__ __forceinline__ void cmac2(float4& acc, const float4& x, const float4& h) {
     acc.x = fmaf(x.x, h.x, acc.x); acc.x = fmaf(-x.y, h.y, acc.x);
@@ -101,11 +89,6 @@ __device__ __forceinline__ bool mask_bit(uint64_t lo, uint64_t hi, uint64_t top,
 __device__ __forceinline__ void peak_raise(unsigned int* p, float v) {
     const unsigned int bits = __float_as_uint(v);
     if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
-}
-
-__device__ __forceinline__ int ring_slot(int slot0, int rel, int ring) {
-    int s = (slot0 + rel) % ring;
-    return s < 0 ? s + ring : s;
 }
 
 // After stage B left Z (P-point FFT of z[m] = x[2m] + i x[2m+1]) in the LDS rows,
@@ -1563,25 +1546,6 @@ __global__ __launch_bounds__(256, (TT * NB <= 16) ? 4 : 1) void mac_slide_kernel
 //   one path per output (the launcher checks), K <= KR; bin 0 (packed DC / Nyquist: two real spectra) falls out of
 //   the same instructions, the re-part and im-part accumulators being kept apart until the store.
 // ---------------------------------------------------------------------------
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-// f(0) && f(1) && ... && f(N-1): straight-line code with an exit after every step, no joins inside
-template <int... I, class F>
-__device__ __forceinline__ bool static_all_impl(std::integer_sequence<int, I...>, F&& f) {
-    return (f(std::integral_constant<int, I>{}) && ...);
-}
-template <int N, class F>
-__device__ __forceinline__ bool static_all(F&& f) {
-    return static_all_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
 // Several lanes per bin (LPB = 2 or 4) carry filters of more than KR rows: lane `sub` of a bin's group holds rows
 // sub*KR .. sub*KR + KR - 1 of G and a window of the spectra those rows meet — the blocks KR*sub further back in time.
 // Only lane 0 of a group loads from memory.  The element that leaves a lane's window at a step (block t - KR in the
@@ -1592,15 +1556,6 @@ __device__ __forceinline__ bool static_all(F&& f) {
 //
 // Time tiles (`tiles` > 1): a one-stream call does not have enough (bin, output) pairs to fill the chip; its blocks are
 // cut into `tiles` runs of `tile_len`, each walked by its own workgroups (and re-reading the rows of history before it).
-__device__ __forceinline__ float dpp_row_shr1(float v) {
-    // (bound_ctrl: lanes without a source read 0 — no `old` operand to materialise; those lanes' results are never used)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
 //
 // Several PATHS per output (NP = 2 or 4: full filter matrices, e.g. a true-stereo reverb's four paths): the LPB lanes of
 // a bin's group are NP sets of LPP = LPB / NP lanes, one set per input path of the output — its own rows of G, its own
@@ -1762,6 +1717,9 @@ __global__ __launch_bounds__(256, (2 * (2 * KR + D) + 24 + (LPB > 1 ? 16 : 0) <=
                         cmul_im(acc[2 * j + 1], w[(u - j + 2 * W) % W], g[j]);
                     } else {
                         cmac_re(acc[2 * (j % (NACC / 2))], w[(u - j + 2 * W) % W], g[j]);
+#ifdef FOLVE_EXPERIMENT_CUT
+                        if constexpr (j % 2 == 0)           // what-if: three packed FMAs per two rows (wrong results)
+#endif
                         cmac_im(acc[2 * (j % (NACC / 2)) + 1], w[(u - j + 2 * W) % W], g[j]);
                     }
                 });
@@ -1921,12 +1879,12 @@ struct FwdLaunch {
                 // P = 8192: walk consecutive blocks
                 const int runlen = tn.fwd_run > 0 ? tn.fwd_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(WaveGeom<L>::NT);
-                hipLaunchKernelGGL((forward_walker_kernel<L, true>), grid, block, 0, st, jr, f, runlen, 0);
+                FK_LAUNCH(0, (forward_walker_kernel<L, true>), grid, block, st, jr, f, runlen, 0);
                 return hipGetLastError();
             } else if constexpr (L >= 9 && L < 13) {      // 2P >= 1024: the one-transform stereo form exists
                 if (f.twa2) {
                     dim3 grid(max_blocks, 1, njobs), block(WaveGeom<L + 1>::NT);
-                    hipLaunchKernelGGL(forward_dual_kernel<L>, grid, block, 0, st, jr, f);
+                    FK_LAUNCH(0, forward_dual_kernel<L>, grid, block, st, jr, f);
                     return hipGetLastError();
                 }
             }
@@ -1937,7 +1895,7 @@ struct FwdLaunch {
             if (((tn.host_io && !tn.in_resident && tn.fft_form == 0 && (long long)njobs * max_blocks <= 64) ||
                  (tn.fft_form == 4 && (long long)njobs * max_blocks <= 512)) && f.cin == 2 && pairs_ok) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * WaveGeom<L>::NT);
-                hipLaunchKernelGGL((forward_pair_kernel<L, true>), grid, block, 0, st, jr, f);
+                FK_LAUNCH(0, (forward_pair_kernel<L, true>), grid, block, st, jr, f);
                 return hipGetLastError();
             }
         }
@@ -1952,17 +1910,17 @@ struct FwdLaunch {
                 const int runs = (max_blocks + runlen - 1) / runlen;
                 const int wxl = runs >= 8 ? 1 : 0;
                 const dim3 grid = wxl ? dim3(8 * pairs, (runs + 7) / 8, njobs) : dim3(runs, pairs, njobs);
-                hipLaunchKernelGGL((forward_walker_kernel<L, true, true>), grid, dim3(WaveGeom<L>::NT), 0, st, jr, f, runlen, wxl);
+                FK_LAUNCH(0, (forward_walker_kernel<L, true, true>), grid, dim3(WaveGeom<L>::NT), st, jr, f, runlen, wxl);
                 return hipGetLastError();
             }
         }
         if (tn.fft_form != 1 && pairs_ok && f.cin >= 4 && f.cin % 2 == 0) {   // many channels: a workgroup per channel pair
             const dim3 grid = xl ? dim3(8 * (f.cin / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin / 2, njobs);
-            hipLaunchKernelGGL(forward_chpair_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jr, f, xl);
+            FK_LAUNCH(0, forward_chpair_kernel<L>, grid, dim3(WaveGeom<L>::NT), st, jr, f, xl);
             return hipGetLastError();
         }
         const dim3 grid = xl ? dim3(8 * f.cin, (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cin, njobs);
-        hipLaunchKernelGGL(forward_kernel<L>, grid, dim3(WaveGeom<L>::NT), 0, st, jr, f, xl);
+        FK_LAUNCH(0, forward_kernel<L>, grid, dim3(WaveGeom<L>::NT), st, jr, f, xl);
         return hipGetLastError();
     }
 };
@@ -1981,7 +1939,7 @@ struct InvLaunch {
             if (((tn.host_io && tn.fft_form == 0 && (long long)njobs * max_blocks <= 64) ||
                  (tn.fft_form == 4 && (long long)njobs * max_blocks <= 512)) && pairs_ok && f.cout == 2) {
                 dim3 grid(max_blocks, 1, njobs), block(2 * NT);
-                hipLaunchKernelGGL((inverse_pair_kernel<L, true>), grid, block, 0, st, jr, f, Y);
+                FK_LAUNCH(2, (inverse_pair_kernel<L, true>), grid, block, st, jr, f, Y);
                 return hipGetLastError();
             }
             const bool fast = tn.fft_form != 1 && pairs_ok && (f.cout == 1 || f.cout == 2) &&
@@ -1989,8 +1947,8 @@ struct InvLaunch {
             if (fast) {
                 const int runlen = tn.inv_run > 0 ? tn.inv_run : auto_run(njobs, max_blocks);
                 dim3 grid((max_blocks + runlen - 1) / runlen, 1, njobs), block(NT);
-                if (f.cout == 2) hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true>), grid, block, 0, st, jr, f, Y, runlen, 0);
-                else hipLaunchKernelGGL((inverse_walker_kernel<L, 1, true>), grid, block, 0, st, jr, f, Y, runlen, 0);
+                if (f.cout == 2) FK_LAUNCH(2, (inverse_walker_kernel<L, 2, true>), grid, block, st, jr, f, Y, runlen, 0);
+                else FK_LAUNCH(2, (inverse_walker_kernel<L, 1, true>), grid, block, st, jr, f, Y, runlen, 0);
                 return hipGetLastError();
             }
             // many outputs: the walker per output pair (see FwdLaunch)
@@ -2001,18 +1959,18 @@ struct InvLaunch {
                 const int runs = (max_blocks + runlen - 1) / runlen;
                 const int wxl = runs >= 8 ? 1 : 0;
                 const dim3 grid = wxl ? dim3(8 * pairs, (runs + 7) / 8, njobs) : dim3(runs, pairs, njobs);
-                hipLaunchKernelGGL((inverse_walker_kernel<L, 2, true, true>), grid, dim3(NT), 0, st, jr, f, Y, runlen, wxl);
+                FK_LAUNCH(2, (inverse_walker_kernel<L, 2, true, true>), grid, dim3(NT), st, jr, f, Y, runlen, wxl);
                 return hipGetLastError();
             }
         }
         const int xl = max_blocks >= 8 ? 1 : 0;
         if (tn.fft_form != 1 && pairs_ok && f.cout >= 4 && f.cout % 2 == 0) {
             const dim3 grid = xl ? dim3(8 * (f.cout / 2), (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cout / 2, njobs);
-            hipLaunchKernelGGL(inverse_chpair_kernel<L>, grid, dim3(NT), 0, st, jr, f, Y, xl);
+            FK_LAUNCH(2, inverse_chpair_kernel<L>, grid, dim3(NT), st, jr, f, Y, xl);
             return hipGetLastError();
         }
         const dim3 grid = xl ? dim3(8 * f.cout, (max_blocks + 7) / 8, njobs) : dim3(max_blocks, f.cout, njobs);
-        hipLaunchKernelGGL(inverse_kernel<L>, grid, dim3(NT), 0, st, jr, f, Y, xl);
+        FK_LAUNCH(2, inverse_kernel<L>, grid, dim3(NT), st, jr, f, Y, xl);
         return hipGetLastError();
     }
 };
@@ -2166,18 +2124,21 @@ void fill_fft_tables(int log2P, float2* dst, int off[4]) {
 // at least two wavefronts per SIMD: a batch of many streams takes one lane per bin, a lone stream spreads its filter
 // over the lanes of a group and its blocks over time tiles.
 namespace {
-struct WalkShape { int kr, lpb, tiles, tile_len, np; };
 // rows of G per lane for `lpb` lanes per bin: the smallest instantiated window that holds ceil(rows / lpb); 0: none
 // One lane per bin has a finer ladder (13 / 21 / 26 / 29 rows beside 9 / 17 / 33): a window wider than the filter multiplies
 // zeros — SantaLucia's 26 rows (K = 25) in the 33-row window were a fifth of a lone stream's K2 arithmetic.
-int walk_rows_per_lane(int rows, int lpb) {
-    const int need = (rows + lpb - 1) / lpb;
-    if (need <= 9 && lpb != 2) return 9;
-    if (lpb == 1 && need <= 13) return 13;
+// (the finer ladder exists for ONE lane per bin only — `lpb` is the whole group, `np` its path sets: a 2 x 2 matrix's
+// lpb = np = 2 has one lane per path but only the 17 / 33-row instantiations)
+int walk_rows_per_lane(int rows, int lpb, int np) {
+    const int lpp = lpb / np;                                  // lanes per path
+    const int need = (rows + lpp - 1) / lpp;
+    const bool fine = lpb == 1;
+    if (need <= 9 && (lpb == 1 || (lpb == 4 && np != 2))) return 9;   // (9 rows: one lane, or four lanes in one or four sets)
+    if (fine && need <= 13) return 13;
     if (need <= 17) return 17;
-    if (lpb == 1 && need <= 21) return 21;
-    if (lpb == 1 && need <= 26) return 26;
-    if (lpb == 1 && need <= 29) return 29;
+    if (fine && need <= 21) return 21;
+    if (fine && need <= 26) return 26;
+    if (fine && need <= 29) return 29;
     if (need <= 33) return 33;
     return 0;
 }
@@ -2191,8 +2152,7 @@ bool choose_walk(const FilterDev& f, int njobs, int max_blocks, int np, WalkShap
     out->kr = 0;
     out->np = np;
     for (int lpb = np; lpb <= 4; lpb *= 2) {                   // fewest lanes per bin first: least arithmetic overhead,
-        int kr = walk_rows_per_lane(rows, lpb / np);           // widest rows per wavefront
-        if (kr == 9 && lpb == 2) kr = 17;                      // (the instantiated windows: 17 / 33 rows with two lanes, 9 / 17 / 33 otherwise)
+        int kr = walk_rows_per_lane(rows, lpb, np);                // widest rows per wavefront
         if (!kr) continue;
         const long long waves = (long long)njobs * f.cout * (f.P / 64) * lpb;
         int tiles = 1;
@@ -2206,7 +2166,7 @@ bool choose_walk(const FilterDev& f, int njobs, int max_blocks, int np, WalkShap
     return out->kr != 0;
 }
 template <int KR, int D, int LPB, int NP = 1>
-void launch_walk(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, hipStream_t st) {
+void launch_walk(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, const Tuning& tn, hipStream_t st) {
     dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
     // PIN: the window loads issued by inline asm at their step, awaited by hand-counted s_waitcnt (tools/check_isa.py
     // simulates every such loop on the built code object).  `make NO_PIN=1` builds the same walk with compiler-scheduled
@@ -2224,7 +2184,7 @@ void launch_walk(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, con
 #ifndef FOLVE_WALK_NACC
 #define FOLVE_WALK_NACC 4
 #endif
-    hipLaunchKernelGGL((mac_walk_kernel<KR, D, kPin, FOLVE_WALK_NACC, LPB, NP>), grid, block, 0, st, jr, f, Y, w.tiles, w.tile_len);
+    FK_LAUNCH(1, (mac_walk_kernel<KR, D, kPin, FOLVE_WALK_NACC, LPB, NP>), grid, block, st, jr, f, Y, w.tiles, w.tile_len);
 }
 }  // namespace
 
@@ -2241,8 +2201,7 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
                            (unsigned long long)shape.ndata * f.K * f.P * 8ull < (1ull << 32));
     const bool walk_ok = paths_ok && choose_walk(f, njobs, max_blocks, np, &ws);
     if (tn.walk_lpb > 0 && walk_ok) {                           // tests: pin the lanes per bin / the time tiles
-        int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) && tn.walk_lpb >= np ? walk_rows_per_lane(f.K, tn.walk_lpb / np) : 0;
-        if (kr == 9 && tn.walk_lpb == 2) kr = 17;
+        int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) && tn.walk_lpb >= np ? walk_rows_per_lane(f.K, tn.walk_lpb, np) : 0;
         if (kr) { ws.lpb = tn.walk_lpb; ws.kr = kr; }
     }
     if (tn.walk_tiles > 0 && walk_ok) {
@@ -2257,33 +2216,39 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
         else form = 1;
     }
     if (form == 100) {
+        // Three FMAs per complex multiply-add (mac_walk3.hip) wherever that form is instantiated: a quarter less arithmetic
+        // where the walk's time is arithmetic (cfg4's two lanes per bin: K2 121 -> 110 us; a 2 x 2 matrix: 1.74 -> 1.53 ms),
+        // and fewer joules where it is memory (cfg3's batch at the power cap: the whole call 2.25 -> 2.19 ms, K1 and K3
+        // included).  tn.walk_fma pins either form.
+        const bool fma3 = tn.walk_fma == 3 || tn.walk_fma == 0;
+        if (fma3 && walk3_has(ws.kr, ws.lpb, ws.np)) return launch_walk3(jobs, njobs, f, Y, ws, tn, st);
         // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
         // waves start together and read 2 KB of a row between them: DRAM locality)
         if (ws.np == 2 && ws.lpb == 2) {
-            if (ws.kr == 17) launch_walk<17, 15, 2, 2>(jr, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 2, 2>(jr, njobs, f, Y, ws, st);
+            if (ws.kr == 17) launch_walk<17, 15, 2, 2>(jr, njobs, f, Y, ws, tn, st);
+            else launch_walk<33, 7, 2, 2>(jr, njobs, f, Y, ws, tn, st);
         } else if (ws.np == 2) {
-            if (ws.kr == 17) launch_walk<17, 15, 4, 2>(jr, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 4, 2>(jr, njobs, f, Y, ws, st);
+            if (ws.kr == 17) launch_walk<17, 15, 4, 2>(jr, njobs, f, Y, ws, tn, st);
+            else launch_walk<33, 7, 4, 2>(jr, njobs, f, Y, ws, tn, st);
         } else if (ws.np == 4) {
-            if (ws.kr == 9) launch_walk<9, 15, 4, 4>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 17) launch_walk<17, 15, 4, 4>(jr, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 4, 4>(jr, njobs, f, Y, ws, st);
+            if (ws.kr == 9) launch_walk<9, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 17) launch_walk<17, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
+            else launch_walk<33, 7, 4, 4>(jr, njobs, f, Y, ws, tn, st);
         } else if (ws.lpb == 1) {
-            if (ws.kr == 9) launch_walk<9, 7, 1>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 13) launch_walk<13, 7, 1>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 17) launch_walk<17, 7, 1>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 21) launch_walk<21, 7, 1>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 26) launch_walk<26, 7, 1>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 29) launch_walk<29, 7, 1>(jr, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 1>(jr, njobs, f, Y, ws, st);
+            if (ws.kr == 9) launch_walk<9, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 13) launch_walk<13, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 17) launch_walk<17, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 21) launch_walk<21, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 26) launch_walk<26, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 29) launch_walk<29, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            else launch_walk<33, 7, 1>(jr, njobs, f, Y, ws, tn, st);
         } else if (ws.lpb == 2) {
-            if (ws.kr == 17) launch_walk<17, 15, 2>(jr, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 2>(jr, njobs, f, Y, ws, st);
+            if (ws.kr == 17) launch_walk<17, 15, 2>(jr, njobs, f, Y, ws, tn, st);
+            else launch_walk<33, 7, 2>(jr, njobs, f, Y, ws, tn, st);
         } else {
-            if (ws.kr == 9) launch_walk<9, 15, 4>(jr, njobs, f, Y, ws, st);
-            else if (ws.kr == 17) launch_walk<17, 15, 4>(jr, njobs, f, Y, ws, st);
-            else launch_walk<33, 7, 4>(jr, njobs, f, Y, ws, st);
+            if (ws.kr == 9) launch_walk<9, 15, 4>(jr, njobs, f, Y, ws, tn, st);
+            else if (ws.kr == 17) launch_walk<17, 15, 4>(jr, njobs, f, Y, ws, tn, st);
+            else launch_walk<33, 7, 4>(jr, njobs, f, Y, ws, tn, st);
         }
         return hipGetLastError();
     }
@@ -2294,15 +2259,15 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
             const int nt = pv < 256 ? pv : 256;
             const int tiles = (max_blocks + form - 1) / form;
             dim3 grid(pv / nt, f.cout * tiles, njobs), block(nt);
-            if (form == 16) hipLaunchKernelGGL((mac_slide_kernel<16, 1, 4>), grid, block, 0, st, jr, f, Y, tiles);
-            else if (form == 8) hipLaunchKernelGGL((mac_slide_kernel<8, 2, 2>), grid, block, 0, st, jr, f, Y, tiles);
-            else hipLaunchKernelGGL((mac_slide_kernel<4, 2, 2>), grid, block, 0, st, jr, f, Y, tiles);
+            if (form == 16) FK_LAUNCH(1, (mac_slide_kernel<16, 1, 4>), grid, block, st, jr, f, Y, tiles);
+            else if (form == 8) FK_LAUNCH(1, (mac_slide_kernel<8, 2, 2>), grid, block, st, jr, f, Y, tiles);
+            else FK_LAUNCH(1, (mac_slide_kernel<4, 2, 2>), grid, block, st, jr, f, Y, tiles);
             return hipGetLastError();
         }
     }
     if (form == 1 && max_blocks == 1 && njobs <= 8 && P2 >= 64 && tn.mac_form == 0) {
         dim3 grid(P2 / 64, f.cout, njobs), block(64);
-        hipLaunchKernelGGL(mac_small_kernel<11>, grid, block, 0, st, jr, f, Y);
+        FK_LAUNCH(1, mac_small_kernel<11>, grid, block, st, jr, f, Y);
         return hipGetLastError();
     }
     const int nt = P2 < 256 ? P2 : 256;
@@ -2311,11 +2276,11 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     const int tiles = (max_blocks + tt - 1) / tt;
     dim3 grid(P2 / nt, f.cout * tiles, njobs), block(nt);
     switch (tt) {
-        case 1: hipLaunchKernelGGL(mac_kernel<1>, grid, block, 0, st, jr, f, Y, tiles); break;
-        case 2: hipLaunchKernelGGL(mac_kernel<2>, grid, block, 0, st, jr, f, Y, tiles); break;
-        case 4: hipLaunchKernelGGL(mac_kernel<4>, grid, block, 0, st, jr, f, Y, tiles); break;
-        case 8: hipLaunchKernelGGL(mac_kernel<8>, grid, block, 0, st, jr, f, Y, tiles); break;
-        default: hipLaunchKernelGGL(mac_kernel<16>, grid, block, 0, st, jr, f, Y, tiles); break;
+        case 1: FK_LAUNCH(1, mac_kernel<1>, grid, block, st, jr, f, Y, tiles); break;
+        case 2: FK_LAUNCH(1, mac_kernel<2>, grid, block, st, jr, f, Y, tiles); break;
+        case 4: FK_LAUNCH(1, mac_kernel<4>, grid, block, st, jr, f, Y, tiles); break;
+        case 8: FK_LAUNCH(1, mac_kernel<8>, grid, block, st, jr, f, Y, tiles); break;
+        default: FK_LAUNCH(1, mac_kernel<16>, grid, block, st, jr, f, Y, tiles); break;
     }
     return hipGetLastError();
 }

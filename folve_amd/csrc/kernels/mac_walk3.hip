@@ -1,0 +1,318 @@
+// mac_walk3.hip — K2's whole-call walk with THREE real multiply-adds per complex one (round 5).
+//
+// The walk of kernels.hip (`mac_walk_kernel`: one lane owns one bin of one (stream, output) for a whole call, the filter's
+// rows of that bin and a window of the stream's last spectra in registers) spends its time issuing arithmetic wherever the
+// filter is long or an output has several paths (cfg4's 65 rows on two lanes, a 2 x 2 matrix): 66 packed FMAs of 99
+// instructions per step at 33 rows per lane, and a wavefront pays about five cycles per instruction whatever it is
+// (tools/micro/valu_rates.hip).  This form does the same sum with three quarters of the multiplies.  With x = a + ib a
+// window element and g = c + id a filter row,
+//     T = c (a + b)      R = -b (c + d)      I = a (d - c)        Re(x g) = T + R      Im(x g) = T + I
+// and all three are sums over the rows, so a lane keeps, per filter row, (d - c, -(c + d)) as one register pair and c in
+// pairs of rows, per window element (a, b) as loaded and s = a + b in pairs of elements — one add when the element arrives,
+// used by every row it meets — and accumulates
+//     (I, R) += (a, b) * (d - c, -(c + d))       one v_pk_fma_f32 per row, plain operands
+//     T      += s c                              one v_pk_fma_f32 per TWO rows
+// 1.5 packed FMAs per complex multiply-add instead of 2.  The packing of T is where the structure of a convolution gets
+// in the way: row j meets element u - j at step u, so two neighbouring rows meet two neighbouring elements in REVERSE
+// order, and whether they sit in one aligned register pair alternates with the parity of u.  At odd steps they do — the
+// crossed form `op_sel:[1,0,0] op_sel_hi:[0,1,1]` multiplies (s.hi c.lo, s.lo c.hi), both halves belong to T(u).  At even
+// steps the aligned pairs give (s[u-2q] c[2q], s[u-2q+1] c[2q+1]): the low halves are the even rows' products of T(u), the
+// high halves are the odd rows' products of T(u + 2) — every one of them, and every element they need has arrived (the
+// walk waits for step u + 1's element at step u anyway).  So an even step's high half is CARRIED two steps:
+// T(u) = low half now + high half of two steps ago; the first even step's carry is computed from the history before the
+// loop.  W = KR + D is even, so a slot's parity is its block's parity for the whole call.
+//   Bin 0 is packed (DC, Nyquist: two real spectra, products (sum a c, sum b d)): that lane keeps (c, d) in place of
+//   (d - c, -(c + d)) and zeros in place of c, and takes (I, R) as its result — two selects per step, as before.
+//   Rounding: the three sums have the magnitude of |x||g| where the four-FMA form's have |Re|, |Im| — measured agreement
+//   with the four-FMA walk and with float64: tests/test_forms_gpu.py.
+// Everything else — window as prefetch ring, pinned loads with exact s_waitcnt, several lanes per bin with DPP hand-down,
+// several paths per output, time tiles — is the walk of kernels.hip; tools/check_isa.py simulates these loops too.
+#include "walk_common.hpp"
+
+namespace fk {
+namespace {
+
+// s = a + b of a window element, as ONE v_add_f32 (left to itself hipcc pairs the adds of two steps into a v_pk_add_f32
+// behind four v_mov)
+__device__ __forceinline__ float add_ab(const v2f& x) {
+    float s;
+    asm("v_add_f32 %0, %1, %2" : "=v"(s) : "v"(x.x), "v"(x.y));
+    return s;
+}
+__device__ __forceinline__ void pk_mul(v2f& d, const v2f& a, const v2f& b) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void pk_fma(v2f& d, const v2f& a, const v2f& b) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
+// crossed: d.lo (+)= a.hi * b.lo, d.hi (+)= a.lo * b.hi
+__device__ __forceinline__ void pk_mul_x(v2f& d, const v2f& a, const v2f& b) {
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_fma_x(v2f& d, const v2f& a, const v2f& b) {
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(d) : "v"(a), "v"(b));
+}
+
+// The hand-down of a lane set: every lane but the set's head takes the element that leaves its neighbour's window (one DPP
+// row shift per register), the head keeps what its load brought.  (A DPP bank mask cannot do the select: a bank is four
+// CONSECUTIVE lanes of a row, not lane % 4.)
+__device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool head) {
+    const float hx = dpp_row_shr1(leaving.x), hy = dpp_row_shr1(leaving.y);
+    mine.x = head ? mine.x : hx;
+    mine.y = head ? mine.y : hy;
+}
+
+template <int KR, int D, bool PIN, int LPB = 1, int NP = 1>
+__global__ __launch_bounds__(256, (3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8 : 0) <= 168) ? 3 : 2) void mac_walk3_kernel(
+    JobRef jr, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
+    constexpr int W = KR + D;
+    constexpr int KRP = (KR + 1) / 2;                       // pairs of rows
+    static_assert(W % 2 == 0, "a slot's parity must be its block's parity");
+    static_assert(KR >= 2 && 2 * KRP <= W, "rows");
+    static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per bin");
+    static_assert((NP == 1 || NP == 2 || NP == 4) && NP <= LPB, "paths per output");
+    constexpr int LPP = LPB / NP;                           // lanes per path
+    const StreamJob job = fetch_job(jr);
+    const int o = blockIdx.y / tiles;
+    const int tb = (blockIdx.y - o * tiles) * tile_len;     // first block of this workgroup's time tile
+    if (tb >= job.nblocks) return;
+    const int nb = min(tile_len, job.nblocks - tb);
+    const int P = f.P, K = f.K, ring = job.ring;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int bin = tid / LPB, sub = tid % LPB;
+    const int pi = sub / LPP;                               // which of the output's paths this lane works for
+    const int jb = (sub % LPP) * KR;                        // this lane's first row of G
+    const bool head = sub % LPP == 0;                       // the lane of its set that takes the loaded element
+    const unsigned voff = (unsigned)bin * 8u;               // this thread's bin inside any spectrum row
+    const bool packed = bin == 0;
+    const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
+    const size_t yrow0 = (size_t)job.yunit0 + (size_t)o * job.nblocks + tb;
+    if (pe1 > pe0) {
+        const bool path_on = NP == 1 || pi < pe1 - pe0;
+        const PathEntry pth = f.paths[NP == 1 ? pe0 : pe0 + (path_on ? pi : 0)];
+        const float2* __restrict__ Hd = NP == 1 ? f.H + (size_t)pth.data * K * P : f.H;
+        const float2* __restrict__ X = NP == 1 ? job.fdl + (size_t)pth.in_ch * ring * P : job.fdl;
+        const unsigned voff_g = NP == 1 ? voff : voff + (unsigned)pth.data * (unsigned)K * (unsigned)P * 8u;
+        const unsigned voff_x = NP == 1 ? voff : voff + (unsigned)pth.in_ch * (unsigned)ring * (unsigned)P * 8u;
+        auto ldrow_g = [&](const float2* rowbase) -> v2f {
+            return *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)rowbase + voff_g);
+        };
+        auto ldrow = [&](const float2* rowbase) -> v2f {
+            return *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)rowbase + voff_x);
+        };
+        v2f ge[KR], cp[KRP], w[W], sp[W / 2];
+        const v2f sel = packed ? v2f{0.f, 1.f} : v2f{1.f, 0.f};   // (see the reduction)
+        // the filter's rows of this bin: (c, d) -> (d - c, -(c + d)) and c; rows that do not exist are zeros
+        static_for<KRP>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            cp[q] = v2f{0.f, 0.f};
+        });
+        static_for<KR>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const bool on = path_on && jb + j < K;
+            const v2f v = ldrow_g(Hd + (size_t)(on ? jb + j : 0) * P);
+            const float c = on ? v.x : 0.f, d = on ? v.y : 0.f;
+            ge[j].x = packed ? c : d - c;
+            ge[j].y = packed ? d : -(c + d);
+            if constexpr (j % 2 == 0) cp[j / 2].x = packed ? 0.f : c;
+            else cp[j / 2].y = packed ? 0.f : c;
+        });
+        // history: block -j of the lane's frame (the window of lane `sub` starts KR * sub blocks back) in slot W - j, its s beside
+        // it; slot D (block -KR: the first element handed down to the next lane, a zero with one lane per bin) too
+        static_for<W / 2>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            sp[p] = v2f{0.f, 0.f};                           // (slots still in flight hold finite numbers: they are multiplied, by zeros)
+        });
+        static_for<KR>([&](auto jc) {
+            constexpr int j = decltype(jc)::value + 1;      // 1 .. KR
+            constexpr int slot = W - j;
+            if constexpr (LPB == 1 && j == KR) {
+                w[slot] = v2f{0.f, 0.f};
+            } else {
+                const bool on = path_on && jb + j < K;      // (an element no row will ever meet is a zero)
+                const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, on ? tb - j - jb : tb, ring) * P);
+                w[slot] = on ? v : v2f{0.f, 0.f};
+                if constexpr (slot % 2 == 0) sp[slot / 2].x = add_ab(w[slot]);
+                else sp[slot / 2].y = add_ab(w[slot]);
+            }
+        });
+        auto issue = [&](v2f& dst, const float2* rowbase) {
+            if constexpr (PIN) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff_x), "s"(rowbase) : "memory");
+            else dst = ldrow(rowbase);
+        };
+        const float2* xrow = X + (size_t)ring_slot(job.slot0, tb, ring) * P;
+        const float2* const xend = X + (size_t)ring * P;
+        // (past the tile's last block the walk keeps requesting the ring's next rows: always inside the stream's ring, whatever
+        // they hold is never used — and a clamp to the last row would cost five scalar instructions per step)
+        auto advance = [&]() {
+            const float2* nx = xrow + P;
+            xrow = (nx == xend) ? X : nx;
+        };
+        // the first even step's carry: the odd rows' products of T(0), all from the history
+        v2f carry;
+        static_for<KRP>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int p = W / 2 - 1 - q;                 // slots (W - 2 - 2q, W - 1 - 2q): blocks (-2 - 2q, -1 - 2q)
+            if constexpr (q == 0) pk_mul(carry, sp[p], cp[q]);
+            else pk_fma(carry, sp[p], cp[q]);
+        });
+        if constexpr (PIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G and the history have arrived: the count starts here
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            issue(w[d], xrow);
+            advance();
+        }
+        if constexpr (PIN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(D - 1) : "memory");
+        if constexpr (LPP > 1) hand_down(w[0], w[D], head);
+        sp[0].x = add_ab(w[0]);
+        float2* __restrict__ yrow = Y + yrow0 * P;          // uniform: advances one row per step
+        for (int t0 = 0; t0 < nb; t0 += W) {
+            const bool more = static_all<W>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int un = (u + 1) % W;              // the next step's slot
+#ifndef FOLVE_W3_NOLOAD                                      // what-if build: ... without its in-loop loads
+                issue(w[(u + D) % W], xrow);
+#endif
+                advance();
+                if constexpr (PIN) {
+#if defined(FOLVE_W3_NOLOAD)
+                    constexpr int N = 63;
+#elif defined(FOLVE_W3_NOSTORE)
+                    constexpr int N = D - 1;
+#else
+                    constexpr int N = (D - 1) + (u < D - 1 ? u : D - 1);
+#endif
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[un]) : "n"(N) : "memory");
+                }
+                if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head);
+                if constexpr (un % 2 == 0) sp[un / 2].x = add_ab(w[un]);
+                else sp[un / 2].y = add_ab(w[un]);
+                // Four (I, R) accumulators and two for T, taken in turn — ir0 ir1 tt0 ir2 ir3 tt1 —: every packed FMA is six
+                // instructions away from the one it depends on.  That is what hipcc's hazard recognizer wants between two
+                // inline-asm statements that touch one register (it cannot see that they are plain VALU, and pads an s_nop
+                // wherever they are fewer than five apart); the statements are volatile so that the order stays this one (left
+                // free, the scheduler groups the accumulators, runs out of T products half way and pads the rest).
+                v2f ir[4], tt[2];
+                static_for<KRP>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    constexpr int j0 = 2 * q, j1 = 2 * q + 1;
+                    // (the (I, R) products are plain packed FMAs: left to the compiler, which knows that they need no wait states;
+                    // between inline-asm statements its hazard recognizer counts none and pads)
+                    if constexpr (j0 < 4) ir[j0 % 4] = w[(u - j0 + 2 * W) % W] * ge[j0];
+                    else ir[j0 % 4] = __builtin_elementwise_fma(w[(u - j0 + 2 * W) % W], ge[j0], ir[j0 % 4]);
+                    if constexpr (j1 < KR) {
+                        if constexpr (j1 < 4) ir[j1 % 4] = w[(u - j1 + 2 * W) % W] * ge[j1];
+                        else ir[j1 % 4] = __builtin_elementwise_fma(w[(u - j1 + 2 * W) % W], ge[j1], ir[j1 % 4]);
+                    }
+                    if constexpr (u % 2 == 0) {              // aligned pairs: low half for T(u), high half for T(u + 2)
+                        constexpr int p = ((u - 2 * q + 2 * W) % W) / 2;
+                        if constexpr (q < 2) pk_mul(tt[q % 2], sp[p], cp[q]);
+                        else pk_fma(tt[q % 2], sp[p], cp[q]);
+                    } else {                                 // crossed: both halves for T(u)
+                        constexpr int p = ((u - 2 * q - 1 + 2 * W) % W) / 2;
+                        if constexpr (q < 2) pk_mul_x(tt[q % 2], sp[p], cp[q]);
+                        else pk_fma_x(tt[q % 2], sp[p], cp[q]);
+                    }
+                });
+                // The reduction is ONE asm block: between separate statements hipcc's hazard recognizer pads an s_nop in front of
+                // every dependent packed add (eight per step), and the hardware interlocks plain VALU dependencies by itself.
+                //   ir[0] = ir[0] + ir[1] + ir[2] + ir[3] = (I, R);  tt[0] = tt[0] + tt[1];
+                //   (T, T) = an even step: low half now + the high half carried from two steps ago; an odd one: low + high;
+                //   sum = (T, T) + (R, I) * sel.lo + (I, R) * sel.hi      sel = (1, 0), the packed lane's (0, 1): it takes (I, R)
+                //   as they are (its T is zero: it keeps zeros in place of c) — two packed FMAs where selects would need the
+                //   halves of a register pair, which an asm operand cannot name.
+                v2f sum;
+                static_assert(KR >= 4 && KRP >= 2, "four (I, R) accumulators and two for T are in use");
+#define FK_W3_HEAD                            \
+    "v_pk_add_f32 %1, %1, %4\n\t"             \
+    "v_pk_add_f32 %3, %3, %8\n\t"             \
+    "v_pk_add_f32 %2, %2, %5\n\t"             \
+    "v_pk_add_f32 %1, %1, %3\n\t"
+#define FK_W3_TAIL                                                           \
+    "v_pk_fma_f32 %0, %1, %7, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"       \
+    "v_pk_fma_f32 %0, %1, %7, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                if constexpr (u % 2 == 0) {
+                    asm(FK_W3_HEAD "v_pk_add_f32 %0, %2, %6 op_sel:[0,1] op_sel_hi:[0,1]\n\t" FK_W3_TAIL
+                        : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
+                        : "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel), "v"(ir[3]));
+                    carry = tt[0];
+                } else {
+                    asm(FK_W3_HEAD "v_pk_add_f32 %0, %2, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t" FK_W3_TAIL
+                        : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
+                        : "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel), "v"(ir[3]));
+                }
+#undef FK_W3_HEAD
+#undef FK_W3_TAIL
+                if constexpr (LPB >= 2) {                    // the group's partial sums: every lane ends up with the total
+                    sum.x += dpp_quad<0xB1>(sum.x); sum.y += dpp_quad<0xB1>(sum.y);
+                }
+                if constexpr (LPB >= 4) {
+                    sum.x += dpp_quad<0x4E>(sum.x); sum.y += dpp_quad<0x4E>(sum.y);
+                }
+#ifdef FOLVE_W3_NOSTORE                                      // what-if build (tools/build_variant.sh): the walk without its stores
+                asm volatile("" : : "v"(sum));
+#else
+                if constexpr (PIN) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(sum), "s"(yrow) : "memory");
+                else *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
+#endif
+                yrow += P;
+                return t0 + u + 1 < nb;
+            });
+            if (!more) break;
+        }
+    } else {
+        // an output without an input path: silence
+        for (int t = 0; t < nb; ++t) gst_v2(Y + (yrow0 + t) * P + bin, v2f{0.f, 0.f});
+    }
+}
+
+template <int KR, int D, int LPB, int NP = 1>
+hipError_t launch3(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, const Tuning& tn, hipStream_t st) {
+    dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
+#ifdef FOLVE_WALK_NO_PIN
+    constexpr bool kPin = false;
+#else
+    constexpr bool kPin = true;
+#endif
+    FK_LAUNCH(1, (mac_walk3_kernel<KR, D, kPin, LPB, NP>), grid, block, st, jr, f, Y, w.tiles, w.tile_len);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// the instantiated shapes: the forms whose time is arithmetic (long filters on several lanes, several paths per output)
+// and the one-lane ladder of lone streams
+bool walk3_has(int kr, int lpb, int np) {
+    if (np == 1 && lpb == 1) return kr == 9 || kr == 13 || kr == 17 || kr == 21 || kr == 26 || kr == 29 || kr == 33;
+    if (np == 1 && lpb == 2) return kr == 17 || kr == 33;
+    if (np == 1 && lpb == 4) return kr == 9 || kr == 17 || kr == 33;
+    if (np == 2) return (lpb == 2 || lpb == 4) && (kr == 17 || kr == 33);
+    if (np == 4) return lpb == 4 && (kr == 9 || kr == 17 || kr == 33);
+    return false;
+}
+
+hipError_t launch_walk3(const StreamJob* jobs, int njobs, const FilterDev& f, float2* Y, const WalkShape& ws, const Tuning& tn,
+                        hipStream_t st) {
+    const JobRef jr = make_job_ref(jobs, tn);
+    if (!walk3_has(ws.kr, ws.lpb, ws.np)) return hipErrorInvalidValue;
+    if (ws.np == 2 && ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 2, 2>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.np == 2) return ws.kr == 17 ? launch3<17, 15, 4, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 4, 2>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.np == 4) {
+        if (ws.kr == 9) return launch3<9, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
+        if (ws.kr == 17) return launch3<17, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
+        return launch3<33, 7, 4, 4>(jr, njobs, f, Y, ws, tn, st);
+    }
+    if (ws.lpb == 1) {
+        switch (ws.kr) {
+            case 9: return launch3<9, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            case 13: return launch3<13, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            case 17: return launch3<17, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            case 21: return launch3<21, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            case 26: return launch3<26, 8, 1>(jr, njobs, f, Y, ws, tn, st);
+            case 29: return launch3<29, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            default: return launch3<33, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+        }
+    }
+    if (ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 2>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.kr == 9) return launch3<9, 15, 4>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.kr == 17) return launch3<17, 15, 4>(jr, njobs, f, Y, ws, tn, st);
+    return launch3<33, 7, 4>(jr, njobs, f, Y, ws, tn, st);
+}
+
+}  // namespace fk

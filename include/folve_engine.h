@@ -198,7 +198,9 @@ enum {
     FE_TUNE_DUPLEX_CAP_MB = 12, /* ... and the most device memory (megabytes per direction) the pipeline may stage a batch in (0: 8192); a
                               batch beyond it, or one the memory cannot be had for, runs with the zero-copy kernels instead of failing */
     FE_TUNE_SPLIT = 11,    /* a lone stream's long call as time tiles whose K1 -> K2 -> K3 chains alternate between the two launch lanes:
-                              0 automatic (2 tiles from 64 blocks on), 1 never, 2 .. 8 tiles */
+                              0 / 1 never (the default: measured slower than one chain), 2 .. 8 tiles; calls longer than the stream's
+                              run-ahead depth (several launch rounds) are not split */
+    FE_TUNE_WALK_FMA = 13, /* K2 whole-call walk: 3 = three multiply-adds per complex one (kernels/mac_walk3.hip), 4 = four, 0 = by shape */
     FE_TUNE_LANES = 5      /* fe_batch_submit: 1 = every batch on the engine's own HIP stream, 0 / 2 = two lanes (batches of different
                               streams overlap: one reads its PCM over the bus while the other writes its results back) */
 };
@@ -212,6 +214,10 @@ int fe_engine_set_profiling(fe_engine *e, int on);
 /* accumulated since the last reset: launches and milliseconds per kernel */
 int fe_engine_get_profile(fe_engine *e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]);
 int fe_engine_reset_profile(fe_engine *e);
+/* The kernels of the engine's most recent launch round, one string per role (FE_K_FORWARD / FE_K_MAC / FE_K_INVERSE): the
+ * template instantiation as rocprofv3 prints it without namespaces and arguments, e.g. "mac_walk_kernel<33, 7, true, 4, 1, 1>".
+ * names[k] must hold `cap` bytes each (96 suffice).  bench.py prints them and accepts a committed profile only for the same kernels. */
+int fe_engine_last_kernels(fe_engine *e, char *forward, char *mac, char *inverse, size_t cap);
 /* What this GPU's HBM delivers to plain streaming kernels (16 bytes per lane, `bytes` per pass, `reps`
  * passes, HIP events): gbs[0] reading, gbs[1] writing, gbs[2] copying (bytes read + written), in GB/s.
  * bench.py prints them beside the nominal 8 TB/s its roofline fraction divides by. */

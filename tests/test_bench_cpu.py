@@ -76,3 +76,61 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_a_profile_applies_only_to_the_kernels_it_was_taken_from():
+    """bench.py takes HBM bytes from profiles/traffic.json only for launches of the SAME kernels (by instantiation name, as
+    the engine reports them) whose times agree: a kernel change that keeps the time must still drop the old profile."""
+    b = _bench()
+    entry = {"profile": "rXX", "bytes": {"mac": 100, "forward": 50}, "avg_ns": {"mac": 1000e3, "forward": 600e3},
+             "kernels": {"mac": "mac_walk_kernel<33, 7, true, 4, 1, 1> grid=1048576", "forward": "forward_walker_kernel<13, true, false> grid=262144"}}
+    ran = {"mac": "mac_walk_kernel<33, 7, true, 4, 1, 1>", "forward": "forward_walker_kernel<13, true, false>", "inverse": "x"}
+    kms = {"mac": 1.05, "forward": 0.61, "inverse": 0.6}
+    assert b.profile_applies(entry, ran, kms, 0.15, 0.0) == (True, None)
+    ok, note = b.profile_applies(entry, dict(ran, mac="mac_walk3_kernel<33, 7, true, 1, 1>"), kms, 0.15, 0.0)
+    assert not ok and "other kernels" in note and "mac_walk3_kernel<33,7,true,1,1>" in note          # same time, other kernel
+    ok, note = b.profile_applies(entry, ran, dict(kms, mac=1.3), 0.15, 0.0)
+    assert not ok and "differs" in note                                                              # same kernel, other time
+    assert b.profile_applies(entry, ran, dict(kms, mac=1.3), 0.15, 0.0, roles=["forward"])[0]         # asked about K1 only
+    assert b.profile_applies({}, ran, kms, 0.15, 0.0) == (False, None)
+    assert b.norm_kernel("mac_kernel<1> grid=524288") == "mac_kernel<1>"
+
+
+def test_every_profiled_kernel_exists_in_the_built_library():
+    """profiles/traffic.json names the kernels its bytes were counted on; each of them must be an instantiation of the
+    library as built (a profile of kernels that no longer exist cannot be matched by bench.py and is dead weight)."""
+    import json
+    import sys
+    import tempfile
+    import pytest
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    objs = [o for o in check_isa.default_objects() if os.path.exists(o)]
+    if not (check_isa.tools_present() and len(objs) == 2):
+        pytest.skip("needs the ROCm llvm tools and the built kernel objects")
+    import ctypes
+    cxa = ctypes.CDLL("libstdc++.so.6").__cxa_demangle
+    cxa.restype = ctypes.c_void_p
+    libc = ctypes.CDLL(None)
+
+    def demangle(m):
+        st = ctypes.c_int(0)
+        p = cxa(m.encode(), None, None, ctypes.byref(st))
+        try:
+            return ctypes.string_at(p).decode() if (st.value == 0 and p) else m
+        finally:
+            if p:
+                libc.free(ctypes.c_void_p(p))
+    b = _bench()
+    built = set()
+    for o in objs:
+        with tempfile.TemporaryDirectory() as tmp:
+            names = [k["name"] for k in check_isa.kernel_metadata(check_isa.extract_code_object(o, tmp))]
+        for line in map(demangle, names):
+            head = line.split("(fk::")[0].split("(float")[0]                 # cut the argument list
+            built.add(b.norm_kernel(head.split("::")[-1]))
+    assert any(n.startswith("mac_walk3_kernel<") for n in built) and any(n.startswith("forward_walker_kernel<") for n in built)
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    missing = [(shape, role, name) for shape, e in tj.items() if isinstance(e, dict)
+               for role, name in (e.get("kernels") or {}).items() if b.norm_kernel(name) not in built]
+    assert not missing, missing

@@ -25,7 +25,7 @@ def _rms(a):
 def tuned(engine):
     """The session engine with every knob back on automatic afterwards."""
     yield engine
-    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0, split=0, duplex_cap_mb=0)
+    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0, split=0, duplex_cap_mb=0, walk_fma=0)
 
 
 def test_xlane_exchange_semantics(engine):
@@ -406,14 +406,18 @@ def test_mac_walk_lanes_per_bin_and_time_tiles(tuned, oracle, size, channels, lp
     assert _rms(ref1[0] - y64) <= TOL
     for lpb in lpbs:
         for tiles in (1, 2, 5):
-            tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_tiles=tiles)
-            st = [flt.open_stream(T) for _ in range(S)]
-            y1 = fa.batch_process(st, xs)
-            y2 = fa.batch_process(st, more)
-            for s in range(S):
-                assert _rms(y1[s] - ref1[s]) <= 2e-6, (lpb, tiles, s)
-                assert _rms(y2[s] - ref2[s]) <= 2e-6, (lpb, tiles, s)
-            assert _rms(y1[0] - y64) <= TOL and _rms(y1[0] - y64) / _rms(y64) <= TOL, (lpb, tiles)
+            # both arithmetic forms of the walk: four FMAs per complex multiply-add (kernels.hip) and three (mac_walk3.hip:
+            # odd and even steps, the carried half, the carry out of the history at the start of every time tile)
+            for fma in (4, 3):
+                tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_tiles=tiles, walk_fma=fma)
+                st = [flt.open_stream(T) for _ in range(S)]
+                y1 = fa.batch_process(st, xs)
+                assert tuned.last_kernels()["mac"].startswith("mac_walk3_kernel<" if fma == 3 else "mac_walk_kernel<"), tuned.last_kernels()
+                y2 = fa.batch_process(st, more)
+                for s in range(S):
+                    assert _rms(y1[s] - ref1[s]) <= 2e-6, (lpb, tiles, fma, s)
+                    assert _rms(y2[s] - ref2[s]) <= 2e-6, (lpb, tiles, fma, s)
+                assert _rms(y1[0] - y64) <= TOL and _rms(y1[0] - y64) / _rms(y64) <= TOL, (lpb, tiles, fma)
 
 
 @pytest.mark.parametrize("case", ["2x2 K32", "2x2 K64", "4to2 K8", "4to2 K16", "4to2 K32", "ragged 3x3"])
@@ -455,18 +459,70 @@ def test_mac_walk_with_several_paths_per_output(tuned, oracle, case):
     assert _rms(ref1[1] - y64) <= TOL
     for lpb in lpbs:
         for tiles in (1, 3):
-            tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_tiles=tiles)
-            st = [flt.open_stream(T) for _ in range(S)]
-            y1 = fa.batch_process(st, xs)
-            y2 = fa.batch_process(st, more)
-            for s_ in range(S):
-                assert _rms(y1[s_] - ref1[s_]) <= 2e-6, (lpb, tiles, s_)
-                assert _rms(y2[s_] - ref2[s_]) <= 2e-6, (lpb, tiles, s_)
-            assert _rms(y1[1] - y64) <= TOL and _rms(y1[1] - y64) / _rms(y64) <= TOL, (lpb, tiles)
-            if cout == 3:
-                assert not y1[0][:, 2].any()
+            for fma in (4, 3):
+                tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_tiles=tiles, walk_fma=fma)
+                st = [flt.open_stream(T) for _ in range(S)]
+                y1 = fa.batch_process(st, xs)
+                assert tuned.last_kernels()["mac"].startswith("mac_walk3_kernel<" if fma == 3 else "mac_walk_kernel<"), tuned.last_kernels()
+                y2 = fa.batch_process(st, more)
+                for s_ in range(S):
+                    assert _rms(y1[s_] - ref1[s_]) <= 2e-6, (lpb, tiles, fma, s_)
+                    assert _rms(y2[s_] - ref2[s_]) <= 2e-6, (lpb, tiles, fma, s_)
+                assert _rms(y1[1] - y64) <= TOL and _rms(y1[1] - y64) / _rms(y64) <= TOL, (lpb, tiles, fma)
+                if cout == 3:
+                    assert not y1[0][:, 2].any()
     sp.reset()
     assert _rms(ref1[1] - sp.run(xs[1])) <= TOL
+
+
+def test_walk_window_for_a_short_filter_matrix(tuned, oracle):
+    """A 2 x 2 matrix of ~2 s reverbs (K + 1 = 12 rows): two path sets of ONE lane each.  One lane per bin has a finer ladder
+    of windows (13 / 21 / 26 / 29 rows) that the path-set forms do not: the launcher must take the 17-row window here, not fall
+    through to the 33-row one (twice the arithmetic), and a lone stereo stream with the same 12 rows takes the 13-row one."""
+    rng = np.random.default_rng(12)
+    size = 90000                                                        # 11 partitions, 12 rows of G
+    paths = {(i, o): [(0, (rng.standard_normal(size) * (1.0 if i == o else 0.3) / np.sqrt(size)).astype(np.float32))]
+             for i in range(2) for o in range(2)}
+    _, flt, _ = make_pair(tuned, oracle, 2, 2, size, paths)
+    P, T, S = flt.block_size, 40, 2
+    xs = [rng.uniform(-1, 1, (T * P - 31 * s, 2)).astype(np.float32) for s in range(S)]
+    tuned.set_tuning(mac_form=1)
+    ref = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+    for fma, name in ((4, "mac_walk_kernel<17, 15, true, 4, 2, 2>"), (3, "mac_walk3_kernel<17, 15, true, 2, 2>")):
+        tuned.set_tuning(mac_form=100, walk_fma=fma, walk_lpb=2)
+        ys = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+        assert tuned.last_kernels()["mac"] == name, tuned.last_kernels()
+        for s in range(S):
+            assert _rms(ys[s] - ref[s]) <= 2e-6
+    diag = {(c, c): paths[(c, c)] for c in range(2)}
+    _, flt1, _ = make_pair(tuned, oracle, 2, 2, size, diag)
+    tuned.set_tuning(mac_form=100, walk_fma=4, walk_lpb=1)
+    fa.batch_process([flt1.open_stream(T) for _ in range(S)], xs)
+    assert tuned.last_kernels()["mac"] == "mac_walk_kernel<13, 7, true, 4, 1, 1>", tuned.last_kernels()
+    tuned.set_tuning(mac_form=100, walk_fma=3, walk_lpb=1)
+    fa.batch_process([flt1.open_stream(T) for _ in range(S)], xs)
+    assert tuned.last_kernels()["mac"] == "mac_walk3_kernel<13, 7, true, 1, 1>", tuned.last_kernels()
+
+
+def test_three_fma_walk_at_cfg3_and_cfg4_shapes_against_float64(tuned, oracle):
+    """The three-FMA walk's rounding (its three sums have the magnitude |x||g|, the four-FMA form's |Re|, |Im|) where it
+    counts: cfg3's filter (K = 32, one lane per bin: 33 rows) and cfg4's (K = 64, two lanes) over calls long enough for the
+    sums to fill, against the float64 linear convolution and against the four-FMA walk."""
+    rng = np.random.default_rng(34)
+    for size, C, lpb in ((262144, 2, 1), (524288, 2, 2)):
+        paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(C)}
+        _, flt, _ = make_pair(tuned, oracle, C, C, size, paths)
+        P, K = flt.block_size, flt.partitions
+        T = K + 40
+        x = rng.uniform(-1, 1, (T * P - 17, C)).astype(np.float32)
+        out = {}
+        for fma in (4, 3):
+            tuned.set_tuning(mac_form=100, walk_lpb=lpb, walk_fma=fma)
+            out[fma] = flt.open_stream(T).process_blocks(x)
+        y64 = oracle.linear_convolution_f64(x, dense_taps(paths, size), C)
+        e3, e4 = _rms(out[3] - y64), _rms(out[4] - y64)
+        assert e4 <= 1e-6 and e3 <= 1e-6 and e3 <= 3 * e4 + 1e-7, (size, e3, e4)
+        assert _rms(out[3] - out[4]) <= 2e-6
 
 
 def test_automatic_walk_shapes_for_one_stream_calls(tuned, oracle):

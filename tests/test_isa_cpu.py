@@ -18,14 +18,16 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_isa  # noqa: E402
 
 OBJ = os.path.join(ROOT, "folve_amd", "csrc", "build", "kernels", "kernels.o")
-pytestmark = pytest.mark.skipif(not (check_isa.tools_present() and os.path.exists(OBJ)),
-                                reason="needs the ROCm llvm tools and the built kernels.o")
+OBJ3 = os.path.join(ROOT, "folve_amd", "csrc", "build", "kernels", "mac_walk3.o")
+pytestmark = pytest.mark.skipif(not (check_isa.tools_present() and os.path.exists(OBJ) and os.path.exists(OBJ3)),
+                                reason="needs the ROCm llvm tools and the built kernels.o / mac_walk3.o")
 
 
 def test_walk_kernels_and_walkers_are_clean():
-    rep = check_isa.run(OBJ)
+    rep = check_isa.run()
     assert rep["ok"], "\n".join(rep["problems"][:40])
-    assert rep["walk_kernels"] >= 10 and rep["walk_loops_simulated"] == rep["walk_kernels"]   # every instantiation is PIN
+    assert rep["walk_kernels"] >= 30 and rep["walk_loops_simulated"] == rep["walk_kernels"]   # every instantiation of both forms is PIN
+    assert sum("mac_walk3_kernel" in n for n in rep["kernels"]) >= 15
     assert rep["walker_kernels"] >= 4
     for name, k in rep["kernels"].items():
         if "walker_kernel" in name:
@@ -35,10 +37,12 @@ def test_walk_kernels_and_walkers_are_clean():
 def test_the_checker_sees_what_it_is_there_for():
     """Mutations of a real walk loop: every wait one load too lenient, a copy of a window register right behind its load,
     one more load in the loop, a scratch access — each must be reported (and the unmutated loop must not)."""
-    with tempfile.TemporaryDirectory() as tmp:
-        co = check_isa.extract_code_object(OBJ, tmp)
-        bodies = {n: b for n, b in check_isa.function_bodies(co, "mac_walk_kernel").items() if not n.endswith(".kd")}
-    assert bodies
+    bodies = {}
+    for obj, want in ((OBJ, "mac_walk_kernel"), (OBJ3, "mac_walk3_kernel")):
+        with tempfile.TemporaryDirectory() as tmp:
+            co = check_isa.extract_code_object(obj, tmp)
+            bodies.update({n: b for n, b in check_isa.function_bodies(co, want).items() if not n.endswith(".kd")})
+    assert any("mac_walk3_kernel" in n for n in bodies) and any("mac_walk_kernel" in n for n in bodies)
     for name, body in bodies.items():
         assert check_isa.check_walk_loop(name, body) == []
         loop = set(check_isa.loop_region(body))

@@ -17,7 +17,11 @@ Checks
      hazard; `s_waitcnt vmcnt(n)` retires all but the n youngest.  Also: no scratch_ / buffer_ / flat_ access and no
      accvgpr traffic in the loop, and loads == stores == KR + D (the ring's size: one load and one store per step).
 
-usage: check_isa.py [--json] [--object PATH]      exit code 0 = clean
+The three-FMA walk (kernels/mac_walk3.hip, `mac_walk3_kernel<KR, D, PIN, LPB, NP>`, its own object file) has the same loop
+structure — one pinned load and one store per step, KR + D steps per round — and is checked the same way; its window of
+(a + b) sums is written by VALU instructions only, so nothing of it is ever in flight.
+
+usage: check_isa.py [--json] [--object PATH]      exit code 0 = clean   (default: kernels.o and mac_walk3.o)
 """
 import json
 import os
@@ -195,48 +199,55 @@ def check_walk_loop(name, body):
     return sorted(set(problems))
 
 
+WALK_NAMES = ("mac_walk_kernel", "mac_walk3_kernel")   # kernels.hip (four FMAs per complex MAC), mac_walk3.hip (three)
+
+
+def default_objects():
+    d = os.path.join(ROOT, "folve_amd", "csrc", "build", "kernels")
+    return [os.path.join(d, "kernels.o"), os.path.join(d, "mac_walk3.o")]
+
+
 def run(obj=None):
+    """obj: one object file, a list of them, or None = every object that holds walk kernels."""
     if not tools_present():
         return {"skipped": "llvm tools not found under " + LLVM}
-    obj = obj or os.path.join(ROOT, "folve_amd", "csrc", "build", "kernels", "kernels.o")
-    if not os.path.exists(obj):
-        return {"skipped": obj + " not built"}
-    problems, report = [], {"object": os.path.relpath(obj, ROOT), "kernels": {}}
-    with tempfile.TemporaryDirectory() as tmp:
-        co = extract_code_object(obj, tmp)
-        meta = kernel_metadata(co)
-        n_walk = n_walker = 0
-        for k in meta:
-            name = k["name"]
-            if "mac_walk_kernel" in name:
-                n_walk += 1
-                if k.get("private_segment_fixed_size", 0) != 0 or k.get("vgpr_spill_count", 0) != 0:
-                    problems.append("%s: scratch %d bytes, %d VGPR spills" % (name, k.get("private_segment_fixed_size", 0), k.get("vgpr_spill_count", 0)))
-                report["kernels"][name] = {"vgprs": k.get("vgpr_count"), "args": demangled_args(name)}
-            elif "forward_walker_kernel" in name or "inverse_walker_kernel" in name:
-                n_walker += 1
-                if k.get("vgpr_count", 0) > 128 or k.get("private_segment_fixed_size", 0) != 0:
-                    problems.append("%s: %d VGPRs (budget 128: two workgroups per CU), scratch %d bytes" %
-                                    (name, k.get("vgpr_count", 0), k.get("private_segment_fixed_size", 0)))
-                report["kernels"][name] = {"vgprs": k.get("vgpr_count")}
-        if n_walk == 0 or n_walker == 0:
-            problems.append("no mac_walk_kernel / walker instantiations found in the code object (%d / %d)" % (n_walk, n_walker))
-        bodies = function_bodies(co, "mac_walk_kernel")
-        checked = 0
-        for name, body in bodies.items():
-            if name.endswith(".kd"):
-                continue
-            p = check_walk_loop(name, body)
-            a = demangled_args(name)
-            if len(a) >= 3 and a[2] == 1:
-                checked += 1
-            problems.extend(p)
-        report["walk_kernels"] = n_walk
-        report["walker_kernels"] = n_walker
-        report["walk_loops_simulated"] = checked
-        report["pinned"] = checked > 0
-        if checked == 0 and any(len(demangled_args(n)) >= 3 and demangled_args(n)[2] == 1 for n in bodies):
-            problems.append("no PIN walk loop was simulated")          # (a NO_PIN=1 build has none: nothing to simulate)
+    objs = default_objects() if obj is None else ([obj] if isinstance(obj, str) else list(obj))
+    for o in objs:
+        if not os.path.exists(o):
+            return {"skipped": o + " not built"}
+    problems, report = [], {"object": [os.path.relpath(o, ROOT) for o in objs], "kernels": {}}
+    n_walk = n_walker = checked = 0
+    for o in objs:
+        with tempfile.TemporaryDirectory() as tmp:
+            co = extract_code_object(o, tmp)
+            meta = kernel_metadata(co)
+            for k in meta:
+                name = k["name"]
+                if any(w in name for w in WALK_NAMES):
+                    n_walk += 1
+                    if k.get("private_segment_fixed_size", 0) != 0 or k.get("vgpr_spill_count", 0) != 0:
+                        problems.append("%s: scratch %d bytes, %d VGPR spills" % (name, k.get("private_segment_fixed_size", 0), k.get("vgpr_spill_count", 0)))
+                    report["kernels"][name] = {"vgprs": k.get("vgpr_count"), "args": demangled_args(name)}
+                elif "forward_walker_kernel" in name or "inverse_walker_kernel" in name:
+                    n_walker += 1
+                    if k.get("vgpr_count", 0) > 128 or k.get("private_segment_fixed_size", 0) != 0:
+                        problems.append("%s: %d VGPRs (budget 128: two workgroups per CU), scratch %d bytes" %
+                                        (name, k.get("vgpr_count", 0), k.get("private_segment_fixed_size", 0)))
+                    report["kernels"][name] = {"vgprs": k.get("vgpr_count")}
+            for want in WALK_NAMES:
+                for name, body in function_bodies(co, want).items():
+                    if name.endswith(".kd"):
+                        continue
+                    problems.extend(check_walk_loop(name, body))
+                    a = demangled_args(name)
+                    if len(a) >= 3 and a[2] == 1:
+                        checked += 1
+    if n_walk == 0 or n_walker == 0:
+        problems.append("no mac_walk_kernel / walker instantiations found in the code objects (%d / %d)" % (n_walk, n_walker))
+    report["walk_kernels"] = n_walk
+    report["walker_kernels"] = n_walker
+    report["walk_loops_simulated"] = checked
+    report["pinned"] = checked > 0
     report["problems"] = problems
     report["ok"] = not problems
     return report

@@ -25,4 +25,5 @@ def run(full, S=64, T=256, size=262144, tune=None):
     k = {n: v["ms"] / v["launches"] for n, v in p.items()}
     print("full matrix" if full else "diagonal   ", {n: round(v, 3) for n, v in k.items()}, "%.1f Gsamples/s" % (S * T * P * 2 / sum(k.values()) / 1e6))
 
-run(False); run(True)
+tune = {k: int(v) for k, v in (kv.split("=") for kv in sys.argv[1].split(","))} if len(sys.argv) > 1 else None   # e.g. walk_fma=4
+run(False, tune=tune); run(True, tune=tune)
