@@ -414,7 +414,7 @@ def cpu_for_config(cfg, budget=2.0):
             "build": "-O3 -march=native on this box" if native else "-O3 -march=x86-64-v3 (prebuilt)"}
 
 
-def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
+def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, longer_calls=True):
     """The `configs` entry of one configuration: rate at T-block calls, per-kernel times, and its roofline — HBM bytes per
     launch from the committed rocprofv3 PMC passes of `python bench.py --only-config <name>` (profiles/traffic.json), used
     only while this run's kernel times agree with the profiled run's."""
@@ -463,7 +463,7 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False):
     # whatever the call's length), so the run-ahead depth the caller chooses sets how much of the
     # roof a lone stream sees.  Reported beside the 256-block figure, never instead of it.
     longer = None
-    if not cfg.get("frames") and T < 1024:
+    if longer_calls and not cfg.get("frames") and T < 1024:
         try:
             r4 = measure_config(T=1024, steps=max(20, steps // 3), tune=tune, dev=dev, check=False, **cfg)
             tb4 = tiled_bytes(P, K, 1024)
@@ -511,8 +511,28 @@ def cpu_baseline_leg(args, P, C, size):
     from oracle import oracle as O      # CPU restatement: the baseline being reported, not the product
     native = O.native_bench_lib() is not None
     cores, host_cpus, cores_why = usable_cpus()
-    zita = bool(ctypes.util.find_library("zita-convolver")) and any(
-        os.path.exists(os.path.join(d, "zita-convolver.h")) for d in ("/usr/include", "/usr/local/include"))
+    # The real libzita-convolver, where this box has it ("additionally time the real thing through the same
+    # harness"): tests/compile/zita_ref.cpp is built against it and runs the same shape — one Convproc per stream, configured as
+    # folve configures it, streams dealt to threads — all cores and one core.  Absent (both boxes seen so far): says why.
+    zita = {"available": False}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import zita_real
+        zexe, zwhy = zita_real.build()
+        if zexe is None:
+            zita["why"] = zwhy
+        else:
+            zb = max(8, int(0.3 * args.cpu_seconds / max(1e-4, zita_real.bench(zexe, C, size, cores, 8, cores)["seconds"] / 8.0)))
+            ra = zita_real.bench(zexe, C, size, cores, zb, cores)
+            r1 = zita_real.bench(zexe, C, size, 1, max(16, zb), 1)
+            zita = {"available": True, "kind": "reference", "unit": "Msamples/s", "zita_major": ra.get("zita_major"),
+                    "value": round(cores * zb * P * C / ra["seconds"] / 1e6, 2), "cores": cores,
+                    "sample": "%d streams x %d blocks x %d ch, %d taps, one Convproc per stream, %d threads, %.1f s" % (cores, zb, C, size, cores, ra["seconds"]),
+                    "one_core": {"value": round(max(16, zb) * P * C / r1["seconds"] / 1e6, 2), "sample": "1 stream x %d blocks, %.1f s" % (max(16, zb), r1["seconds"])},
+                    "what": "libzita-convolver itself through tests/compile/zita_ref.cpp (Convproc configured as /root/reference/zita-fconfig.cc:74-94, "
+                            "blocks as sound-processor.cc:98-127)"}
+    except Exception as ex:  # noqa: BLE001 - a reported extra: never fails the line
+        zita = {"available": False, "why": repr(ex)}
 
     def timed(fn, budget):
         """(all-core rate, sample text, one-core rate, sample text) of one CPU engine, sized to `budget` seconds."""
@@ -595,7 +615,10 @@ def main():
     if args.only_config:
         import torch  # noqa: F401
         tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))} if args.tune else None
-        print(json.dumps({args.only_config: config_line(args.only_config, args.config_blocks, steps=min(args.steps, 300), tune=tune)}))
+        # (--skip longer: without the 1 024-block leg, whose launches can share a kernel and a grid with the 256-block ones —
+        # a profile of this command must not average the two)
+        print(json.dumps({args.only_config: config_line(args.only_config, args.config_blocks, steps=min(args.steps, 300), tune=tune,
+                                                        longer_calls="longer" not in args.skip.split(","))}))
         return
 
     import torch

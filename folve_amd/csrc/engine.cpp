@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "kernels/kernels.h"
+#include "trace.h"
 
 namespace {
 
@@ -95,6 +96,7 @@ struct fe_engine {
     float* dx_stage_out[2] = {};         // ... and output staging when the results leave by DMA too (FE_TUNE_DUPLEX_OUT = 2)
     size_t dx_stage_out_bytes[2] = {};
     int dx_stage_idle[2] = {}, dx_stage_out_idle[2] = {};   // consecutive batches that needed less than a quarter of the staging
+    int dx_quiet = 0;                    // consecutive batches that did not take the duplex pipeline at all (its staging is let go after 256)
     hipEvent_t dx_k3[16] = {};           // "K3 of chunk c has finished"
     // per-block maxima of submitted batches (fe_batch_submit_peaks): a few rotating device / page-locked pairs
     struct PeakBuf {
@@ -342,6 +344,9 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
     tn.one_job = nj == 1 ? e->jobs_host[slot] : nullptr;
     tn.names = &e->last_names;
+    // (roctx, when a profiler listens: the three launches of this round under one named range)
+    ftrace::Range round_range("folve round: filter %p (%d->%d ch, K=%d, P=%d) streams=%d blocks<=%d lane=%d", static_cast<void*>(f), f->ninp,
+                              f->nout, f->K, f->P, nj, max_blocks, lane);
     if (prof) HIP_TRY(hipEventRecord(e->pev[0], st));
     HIP_TRY(fk::launch_forward(dj, nj, max_blocks, f->dev, in_pairs_ok, tn, st));
     if (after_k1) HIP_TRY(hipEventRecord(after_k1, st));
@@ -583,6 +588,24 @@ void plan_duplex(fe_stream* const* streams, int n, const long long* nframes, int
     }
     p->first[++p->nc] = n;
 }
+// After a burst of big batches the traffic may consist of small ones only (single blocks, short run-ahead chunks): those
+// never reach run_duplex, whose own shrink logic would therefore never run, and up to 1.25 x the cap per direction and
+// parity would stay allocated for the life of the process.  Counted on the submit path; the staging goes once 256 batches
+// in a row have passed it by and the batches that last used it have finished.
+void release_idle_duplex_staging(fe_engine* e) {
+    if (++e->dx_quiet < 256) return;
+    e->dx_quiet = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (!e->dx_stage[i] && !e->dx_stage_out[i]) continue;
+        if (e->dx_free_pending[i]) {
+            if (hipEventQuery(e->dx_free[i]) != hipSuccess) { (void)hipGetLastError(); continue; }   // still in use: next time
+            e->dx_free_pending[i] = false;
+        }
+        if (e->dx_stage[i]) { (void)hipFree(e->dx_stage[i]); e->dx_stage[i] = nullptr; e->dx_stage_bytes[i] = 0; e->dx_stage_idle[i] = 0; }
+        if (e->dx_stage_out[i]) { (void)hipFree(e->dx_stage_out[i]); e->dx_stage_out[i] = nullptr; e->dx_stage_out_bytes[i] = 0; e->dx_stage_out_idle[i] = 0; }
+    }
+}
+
 int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, int n, const float* const* host_in,
                float* const* host_out, const long long* nframes, int lane, const DuplexPlan& p,
                unsigned int* pk_dev = nullptr, unsigned int* pk_host = nullptr, size_t pk_bytes = 0) {
@@ -640,7 +663,11 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
             need_out += (((size_t)nframes[i] * streams[i]->f->nout + 3) & ~(size_t)3) * sizeof(float);
         }
         if (need_out > stage_cap) return fail(FE_ERR_UNSUPPORTED, "batch of %zu bytes exceeds the duplex staging cap: it runs zero-copy", need_out);
-        if (int rc = fit_stage(e->dx_stage_out[par], e->dx_stage_out_bytes[par], need_out, e->dx_stage_out_idle[par])) return rc;
+        if (int rc = fit_stage(e->dx_stage_out[par], e->dx_stage_out_bytes[par], need_out, e->dx_stage_out_idle[par])) {
+            // the output side was refused: the batch runs zero-copy, and the input staging grown for it a moment ago is of no use
+            if (e->dx_stage[par]) { (void)hipFree(e->dx_stage[par]); e->dx_stage[par] = nullptr; e->dx_stage_bytes[par] = 0; e->dx_stage_idle[par] = 0; }
+            return rc;
+        }
     }
     struct HostOutScope {                // with the results leaving by DMA the kernels see device memory on both sides
         fe_engine* e; bool was;
@@ -663,6 +690,7 @@ int run_duplex(fe_engine* e, fe_stream* const* streams, std::vector<Item>& all, 
     }
     for (int c = 0; c < nc; ++c) {
         const int l = (lane + c) & 1;
+        ftrace::Range chunk_range("folve duplex chunk %d/%d: streams %d..%d, copy in -> lane %d -> copy out", c + 1, nc, first[c], first[c + 1] - 1, l);
         for (int i = first[c]; i < first[c + 1]; ++i) {
             const size_t bytes = (size_t)nframes[i] * streams[i]->f->ninp * sizeof(float);
             float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(e->dx_stage[par]) + off[(size_t)i]);
@@ -903,6 +931,8 @@ int process_locked(fe_engine* e, fe_stream* const* streams, int n, const float* 
             }
         }
         if (pk_dev && !duplex) HIP_TRY(hipMemsetAsync(pk_dev, 0, pk_bytes, st));
+        if (duplex) e->dx_quiet = 0;
+        else release_idle_duplex_staging(e);
         int rc = duplex ? run_duplex(e, streams, all, n, host_in, host_out, nframes, lane, dplan, pk_dev, pk_host, pk_bytes)
                         : run_groups(e, streams, all, 0, n, lane, nullptr, /*spread=*/true);
         if (rc == FE_ERR_UNSUPPORTED && duplex) {

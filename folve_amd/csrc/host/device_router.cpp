@@ -48,8 +48,18 @@ DeviceRouter::DeviceRouter(const std::vector<int>& devices) {
 
 DeviceRouter::~DeviceRouter() {
     {
-        std::unique_lock<std::mutex> lk(mu_);        // a probe thread still out there touches the slots
-        probed_.wait(lk, [this] { return probes_in_flight_ == 0; });
+        // A probe thread still out there touches the slots: wait for it — for a bounded time.  A probe that hangs for good
+        // (the case its thread is detached for) must not hang the teardown too: then the slots and engines are left to
+        // the process's end instead of being destroyed under a thread that may still wake up.
+        std::unique_lock<std::mutex> lk(mu_);
+        const bool quiet = probed_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds(10),
+                                              [this] { return probes_in_flight_ == 0; });
+        if (!quiet) {
+            Logf("DeviceRouter: a GPU probe has not come back after 10 s: leaving %zu slots to the end of the process", slots_.size());
+            for (auto& sp : slots_) (void)sp.release();                          // (leaked on purpose: the probe thread holds pointers into them)
+            filters_.clear();
+            return;
+        }
     }
     for (auto& kv : filters_) fe_filter_release(kv.second.filter);
     for (auto& s : slots_)
@@ -98,8 +108,8 @@ bool DeviceRouter::ProbeSlot(Slot* s, std::unique_lock<std::mutex>* lk) {
             }
             s->probing = false;
             probes_in_flight_--;
+            probed_.notify_all();                    // (under the lock: ~DeviceRouter may destroy the condition variable the moment it sees 0)
         }
-        probed_.notify_all();
     };
     try {
         std::thread(look).detach();
@@ -130,6 +140,9 @@ fe_engine* DeviceRouter::PickEngine(const std::vector<fe_engine*>* tried) {
         return false;
     };
     std::set<const Slot*> gave_up;                   // slots this very call has probed (or waited for) without success
+    // What one open may spend on probes and waits in all: with every GPU hung, each slot in turn would cost a probe wait
+    // (8 x 2 s per open); past this point sick slots are no longer looked at and the open takes what is healthy, or fails.
+    const double t_end = Now() + 2.0 * probe_wait_s_ + 0.5;
     for (;;) {
         const double now = Now();
         Slot* best = NULL;
@@ -148,11 +161,12 @@ fe_engine* DeviceRouter::PickEngine(const std::vector<fe_engine*>* tried) {
             if (st == kFenced) continue;
             if (!best || st < best->state.load() || (st == best->state.load() && s->live < best->live)) best = s;
         }
-        if (due) {
+        if (due && now < t_end) {
             if (!ProbeSlot(due, &lk)) gave_up.insert(due);
             continue;                                // choose again with what the probe found
         }
         if (!best) {
+            if (now >= t_end) return NULL;
             if (sick) {
                 if (!ProbeSlot(sick, &lk)) gave_up.insert(sick);
                 continue;
@@ -228,7 +242,8 @@ void DeviceRouter::ReportFailure(fe_engine* e) {
         s->state.store(now);
         if (now == kFenced)
             Logf("GPU %d (slot %d) fenced after %d consecutive failures: new files go to the other GPUs", s->device,
-                 static_cast<int>(s - slots_[0].get()), s->fail_streak);
+                 static_cast<int>(std::find_if(slots_.begin(), slots_.end(), [&](const std::unique_ptr<Slot>& q) { return q.get() == s; }) - slots_.begin()),
+                 s->fail_streak);
     }
 }
 

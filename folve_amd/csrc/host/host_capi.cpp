@@ -146,6 +146,8 @@ int fh_processor_device(const fh_processor* p) { return SP(p)->device(); }
 fe_stream* fh_processor_stream(const fh_processor* p) { return SP(p)->stream(); }
 fe_engine* fh_processor_engine(const fh_processor* p) { return SP(p)->engine(); }
 int fh_processor_ok(const fh_processor* p) { return SP(p)->ok() ? 1 : 0; }
+int fh_processor_moves(const fh_processor* p) { return SP(p)->moves(); }
+void fh_survival_set(int on) { SoundProcessor::SetSurvival(on != 0); }
 
 fh_pool* fh_pool_create(int max_per_config) { return reinterpret_cast<fh_pool*>(new ProcessorPool(max_per_config)); }
 void fh_pool_destroy(fh_pool* pool) { delete PP(pool); }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "device_router.h"
+#include "../trace.h"
 #include "sound_processor.h"
 
 namespace folve {
@@ -79,18 +80,23 @@ SoundProcessor* ProcessorPool::GetOrCreate(const std::string& base_dir, int samp
         }
         break;
     }
-    if (result != NULL) return result;
+    if (result != NULL) {
+        if (ftrace::events_on()) ftrace::event("GetOrCreate pooled processor=%p gpu=%d config=%s", static_cast<void*>(result), result->device(), config_path.c_str());
+        return result;
+    }
 
     result = SoundProcessor::Create(config_path, sampling_rate, channels);
     if (result == NULL) {
         *errmsg = "Problem parsing " + config_path;
         Logf("filter-config %s is broken.", config_path.c_str());
     }
+    if (ftrace::events_on()) ftrace::event("GetOrCreate created processor=%p gpu=%d config=%s", static_cast<void*>(result), result ? result->device() : -1, config_path.c_str());
     return result;
 }
 
 void ProcessorPool::Return(SoundProcessor* processor) {
     if (processor == NULL) return;
+    if (ftrace::events_on()) ftrace::event("Return processor=%p gpu=%d ok=%d moves=%d peak=%g", static_cast<void*>(processor), processor->device(), (int)processor->ok(), processor->moves(), processor->max_output_value());
     if (!processor->ConfigStillUpToDate()) {
         delete processor;     // outdated: not returning it to the pool
         return;

@@ -17,10 +17,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
+#include <vector>
 
 #include "batch_scheduler.h"
 #include "device_router.h"
 #include "numa_placement.h"
+#include "../trace.h"
 
 namespace folve {
 
@@ -33,6 +36,7 @@ static time_t GetModificationTime(const std::string& filename) {
 namespace {
 std::atomic<int> g_run_ahead{-2};          // -2: not decided yet (environment); -1: automatic (by block size)
 std::atomic<bool> g_device_peaks{true};
+std::atomic<int> g_survive{-1};            // -1: not decided yet (FOLVE_AMD_SURVIVE, default on)
 const int kMaxRunAhead = 1024;
 // 64 blocks = 12 s of 44.1 kHz audio per chunk: 8 MB of page-locked ring and 12.6 MB of delay line per open stereo file
 // at 256 k taps.  Measured with 64 file threads on one MI355X: depth 8: 5.5, 32: 8.0, 64: 9.0, 128: 9.2 Gsamples/s.
@@ -44,6 +48,18 @@ const size_t kRingBudgetBytes = static_cast<size_t>(64) << 20;
 }  // namespace
 
 void SoundProcessor::SetDevicePeaks(bool on) { g_device_peaks.store(on); }
+
+void SoundProcessor::SetSurvival(bool on) { g_survive.store(on ? 1 : 0); }
+
+static bool SurvivalWanted() {
+    int v = g_survive.load();
+    if (v < 0) {
+        const char* env = getenv("FOLVE_AMD_SURVIVE");
+        v = (env && atoi(env) == 0 && env[0] == '0') ? 0 : 1;
+        g_survive.store(v);
+    }
+    return v != 0;
+}
 
 void SoundProcessor::SetRunAhead(int blocks) { g_run_ahead.store(blocks <= 0 ? -1 : std::min(blocks, kMaxRunAhead)); }
 
@@ -136,9 +152,9 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     if (NumaPlacement()) {
         // page-locked pages land where the allocating thread runs: next to the GPU that will read them
         ScopedDeviceAffinity near_gpu(fe_engine_device(engine));
-        return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files);
+        return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files, samplerate, channels);
     }
-    return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files);
+    return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files, samplerate, channels);
 }
 
 // The block buffer (`buffer_`, sound-processor.cc:62-63: fragm * max(ninp, nout) floats, reused in
@@ -165,9 +181,10 @@ static size_t ChunkFloats(const ZitaConfig& c, int depth) {
 }
 
 SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream, int run_depth,
-                               const std::vector<std::pair<std::string, time_t>>& impulse_files)
+                               const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels)
     : zita_config_(config), config_file_(cfg), config_file_timestamp_(GetModificationTime(cfg)), impulse_files_(impulse_files),
-      stream_(stream),
+      samplerate_(samplerate), channels_(channels), engine_(config.engine),
+      stream_(stream), hist_(NULL), hist_cap_(0), hist_k_(0), blocks_fed_(0), moves_(0),
       run_depth_(run_depth),
       buffer_floats_(static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)),
       arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth)),
@@ -190,31 +207,38 @@ SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg,
         tail_ = new float[static_cast<size_t>(config.fragm) * config.ninp];
         for (Chunk& c : chunks_) c.peaks = new float[2 * static_cast<size_t>(run_depth_)];
     }
+    // the input history an open file needs to move to another GPU: K blocks of state + the longest call's own input
+    if (SurvivalWanted()) {
+        hist_k_ = config.fragm > 0 ? static_cast<int>((static_cast<long long>(config.size) + config.fragm - 1) / config.fragm) : 0;
+        const long long cap = static_cast<long long>(hist_k_) + std::max(run_depth_, 1);
+        const size_t bytes = static_cast<size_t>(cap) * config.fragm * config.ninp * sizeof(float);
+        if (hist_k_ > 0 && bytes <= kRingBudgetBytes) {
+            hist_ = new (std::nothrow) float[bytes / sizeof(float)];
+            if (hist_) hist_cap_ = static_cast<int>(cap);
+        }
+        if (!hist_) Logf("Processor %p: no input history kept (%zu bytes): a GPU failure under it ends in silence", static_cast<void*>(this), bytes);
+    }
     Reset();
 }
 
 SoundProcessor::~SoundProcessor() {
     DrainRing();                         // a request still on the GPU writes into the ring
     fe_stream_close(stream_);
-    DeviceRouter::Default()->StreamClosed(zita_config_.engine);
+    DeviceRouter::Default()->StreamClosed(engine_);
+    delete[] hist_;
     if (buffer_pinned_) fe_host_free(buffer_);
     else delete[] buffer_;
     delete[] tail_;
     for (Chunk& c : chunks_) delete[] c.peaks;
 }
 
-int SoundProcessor::device() const { return fe_engine_device(zita_config_.engine); }
+int SoundProcessor::device() const { return fe_engine_device(engine_); }
 
-// What the GPU sharder hears of this processor's engine calls: every failure, and a success only while the slot is
-// not healthy (one relaxed load otherwise).
-void SoundProcessor::EngineCallFailed() {
-    ok_ = false;                         // ProcessorPool::Return will not pool this processor
-    DeviceRouter::Default()->ReportFailure(zita_config_.engine);
-}
-
+// What the GPU sharder hears of this processor's engine calls: every failure (at the call sites), and a success only
+// while the slot is not healthy (one relaxed load otherwise).
 void SoundProcessor::EngineCallSucceeded() {
     if (slot_health_ && slot_health_->load(std::memory_order_relaxed) != 0 && ok_)
-        DeviceRouter::Default()->ReportSuccess(zita_config_.engine);
+        DeviceRouter::Default()->ReportSuccess(engine_);
 }
 
 // Ask the source for the next chunk (depth_next_ whole blocks).  Whole blocks stay in the chunk; frames beyond
@@ -241,17 +265,23 @@ bool SoundProcessor::ReadChunk(FrameSource* in, Chunk* c) {
 void SoundProcessor::SubmitChunk(Chunk* c) {
     const long long frames = static_cast<long long>(c->blocks) * zita_config_.fragm;
     c->peaks_valid = false;
+    c->first = blocks_fed_;
+    KeepInput(c->in, c->blocks, zita_config_.fragm);        // (the call may overwrite its input in place)
+    if (ftrace::events_on()) ftrace::event("submit processor=%p gpu=%d first_block=%lld blocks=%d", static_cast<void*>(this), device(), c->first, c->blocks);
     if (BatchScheduler::Enabled()) {
-        c->request = BatchScheduler::ForEngine(zita_config_.engine)->Submit(stream_, c->in, frames, c->out,
-                                                                             g_device_peaks.load() ? c->peaks : NULL);
+        c->request = BatchScheduler::ForEngine(engine_)->Submit(stream_, c->in, frames, c->out,
+                                                                g_device_peaks.load() ? c->peaks : NULL);
         return;
     }
     c->request = NULL;
     const int rc = fe_stream_process_blocks(stream_, c->in, frames, c->out);
     if (rc != 0) {
         Logf("GPU convolution failed (%d): %s", rc, fe_last_error());
-        memset(c->out, 0, sizeof(float) * frames * output_channels());
-        EngineCallFailed();
+        DeviceRouter::Default()->ReportFailure(engine_);
+        if (!MoveToAnotherGpu(c->first, c->blocks, frames, c->out)) {
+            memset(c->out, 0, sizeof(float) * frames * output_channels());
+            ok_ = false;
+        }
     } else {
         EngineCallSucceeded();
     }
@@ -260,15 +290,96 @@ void SoundProcessor::SubmitChunk(Chunk* c) {
 void SoundProcessor::SettleChunk(Chunk* c) {
     if (!c->request) return;
     std::string error;
-    const int rc = BatchScheduler::ForEngine(zita_config_.engine)->Wait(static_cast<BatchScheduler::Request*>(c->request), &error,
-                                                                       &c->peaks_valid);
+    const int rc = BatchScheduler::ForEngine(engine_)->Wait(static_cast<BatchScheduler::Request*>(c->request), &error,
+                                                            &c->peaks_valid);
     c->request = NULL;
+    if (ftrace::events_on()) ftrace::event("settle processor=%p gpu=%d first_block=%lld blocks=%d rc=%d", static_cast<void*>(this), device(), c->first, c->blocks, rc);
     if (rc != 0) {
         Logf("GPU convolution failed (%d): %s", rc, error.c_str());
-        memset(c->out, 0, sizeof(float) * static_cast<size_t>(c->blocks) * zita_config_.fragm * output_channels());
-        EngineCallFailed();
+        DeviceRouter::Default()->ReportFailure(engine_);
+        c->peaks_valid = false;                              // (whatever the failed call left: the blocks are scanned when handed out)
+        const long long frames = static_cast<long long>(c->blocks) * zita_config_.fragm;
+        if (!MoveToAnotherGpu(c->first, c->blocks, frames, c->out)) {
+            memset(c->out, 0, sizeof(float) * static_cast<size_t>(frames) * output_channels());
+            ok_ = false;
+        }
     } else {
         EngineCallSucceeded();
+    }
+}
+
+// The input of blocks about to go to the engine, into the history ring (block b in slot b % hist_cap_); a short last
+// block is padded with the zeros the engine assumes behind it.
+void SoundProcessor::KeepInput(const float* in, int blocks, int last_frames) {
+    const size_t bf = static_cast<size_t>(zita_config_.fragm) * input_channels();
+    if (hist_) {
+        for (int b = 0; b < blocks; ++b) {
+            float* dst = hist_ + static_cast<size_t>((blocks_fed_ + b) % hist_cap_) * bf;
+            const size_t n = (b == blocks - 1 ? static_cast<size_t>(last_frames) : static_cast<size_t>(zita_config_.fragm)) * input_channels();
+            memcpy(dst, in + static_cast<size_t>(b) * bf, n * sizeof(float));
+            if (n < bf) memset(dst + n, 0, (bf - n) * sizeof(float));
+        }
+    }
+    blocks_fed_ += blocks;
+}
+
+// See the head of sound_processor.h.  The history ring holds blocks [blocks_fed_ - hist_cap_, blocks_fed_); the failed
+// call's blocks are its newest `blocks`, the state in front of them the hist_k_ blocks before.
+bool SoundProcessor::MoveToAnotherGpu(long long first, int blocks, long long frames, float* out) {
+    if (!hist_ || blocks <= 0 || blocks + hist_k_ > hist_cap_ || first + blocks != blocks_fed_) return false;
+    DeviceRouter* router = DeviceRouter::Default();
+    const int P = zita_config_.fragm;
+    const size_t bf = static_cast<size_t>(P) * input_channels();
+    const long long replay0 = std::max<long long>(0, first - hist_k_);
+    const long long nrep = first - replay0;
+    // the kept blocks in order, contiguous (the ring wraps): [replay | the failed call's own input]
+    std::vector<float> in(static_cast<size_t>(nrep + blocks) * bf);
+    for (long long b = replay0; b < first + blocks; ++b)
+        memcpy(in.data() + static_cast<size_t>(b - replay0) * bf, hist_ + static_cast<size_t>(b % hist_cap_) * bf, bf * sizeof(float));
+    std::vector<float> scratch(static_cast<size_t>(std::max<long long>(nrep, 1)) * P * output_channels());
+    std::vector<fe_engine*> tried(1, engine_);
+    for (;;) {
+        fe_engine* e = router->PickEngine(&tried);          // (reserves a stream there)
+        if (!e) {
+            Logf("Processor %p: its GPU failed and no other can take the stream: silence from here", static_cast<void*>(this));
+            return false;
+        }
+        bool engine_fault = false;
+        ZitaConfig z;
+        memset(&z, 0, sizeof(z));
+        fe_filter* filter = router->GetFilter(e, config_file_, config_file_timestamp_, samplerate_, channels_, &z, NULL, &engine_fault);
+        fe_stream* ns = NULL;
+        bool same = filter && z.fragm == zita_config_.fragm && z.ninp == zita_config_.ninp && z.nout == zita_config_.nout &&
+                    z.size == zita_config_.size;
+        int rc = same ? fe_stream_open(filter, run_depth_, &ns) : -1;
+        if (filter) fe_filter_release(filter);
+        if (same && rc != 0) engine_fault = true;
+        if (rc == 0 && nrep > 0) rc = fe_stream_process_blocks(ns, in.data(), nrep * P, scratch.data());     // the delay line, rebuilt
+        if (rc == 0) rc = fe_stream_process_blocks(ns, in.data() + static_cast<size_t>(nrep) * bf, frames, out);
+        if (rc == 0) {
+            fe_stream_close(stream_);
+            router->StreamClosed(engine_);
+            Logf("Processor %p (%s): GPU %d failed under it; the stream moved to GPU %d (%lld blocks of state replayed, %d re-run)",
+                 static_cast<void*>(this), config_file_.c_str(), fe_engine_device(engine_), fe_engine_device(e), nrep, blocks);
+            if (ftrace::events_on()) ftrace::event("move processor=%p gpu=%d->%d replayed=%lld rerun=%d", static_cast<void*>(this), fe_engine_device(engine_), fe_engine_device(e), nrep, blocks);
+            engine_ = e;
+            stream_ = ns;
+            slot_health_ = router->HealthFlag(e);
+            if (buffer_pinned_ && fe_stream_bind_host_buffer(stream_, buffer_, arena_floats_ * sizeof(float)) != 0)
+                Logf("Processor %p: block buffer not bound on the new GPU (%s): blocks will be staged", static_cast<void*>(this), fe_last_error());
+            ++moves_;
+            return true;
+        }
+        if (ns) fe_stream_close(ns);
+        router->StreamClosed(e);                             // give the reservation back
+        if (!same && !engine_fault) {
+            Logf("Processor %p: %s no longer yields the filter this stream was opened with: the stream cannot move", static_cast<void*>(this),
+                 config_file_.c_str());
+            return false;
+        }
+        Logf("Processor %p: GPU %d could not take the stream either (%s)", static_cast<void*>(this), fe_engine_device(e), fe_last_error());
+        router->ReportFailure(e);
+        tried.push_back(e);
     }
 }
 
@@ -382,8 +493,10 @@ void SoundProcessor::Process() {
         // block is in flight on this GPU it is parked and leaves with the next batch.
         std::string error;
         int rc;
+        const long long first = blocks_fed_;
+        KeepInput(buffer_, 1, input_pos_);                   // (the block is computed in place)
         if (BatchScheduler::Enabled()) {
-            rc = BatchScheduler::ForEngine(zita_config_.engine)->Process(stream_, buffer_, input_pos_, buffer_, &error);
+            rc = BatchScheduler::ForEngine(engine_)->Process(stream_, buffer_, input_pos_, buffer_, &error);
         } else {
             rc = fe_stream_process(stream_, buffer_, input_pos_, buffer_, NULL, NULL);
             if (rc != 0) error = fe_last_error();
@@ -391,8 +504,13 @@ void SoundProcessor::Process() {
         const size_t n = static_cast<size_t>(input_pos_) * output_channels();
         if (rc != 0) {
             Logf("GPU convolution failed (%d): %s", rc, error.c_str());
-            memset(buffer_, 0, sizeof(float) * n);
-            EngineCallFailed();
+            DeviceRouter::Default()->ReportFailure(engine_);
+            if (MoveToAnotherGpu(first, 1, input_pos_, buffer_)) {
+                ScanPeaks(buffer_, n);
+            } else {
+                memset(buffer_, 0, sizeof(float) * n);
+                ok_ = false;
+            }
         } else {
             ScanPeaks(buffer_, n);
             EngineCallSucceeded();
@@ -416,6 +534,7 @@ void SoundProcessor::ResetMaxValues() {
 void SoundProcessor::Reset() {
     DrainRing();
     fe_stream_reset(stream_);
+    blocks_fed_ = 0;                     // (a reset stream has no state: nothing before this point would be replayed)
     input_pos_ = 0;
     output_pos_ = -1;
     ResetMaxValues();

@@ -27,6 +27,16 @@
 // construction.  max_output_value() advances block by block as blocks are handed out, not as they are computed: K3 reduces
 // every block's maxima on the GPU (fe_batch_submit_peaks) and the processor folds a block's two numbers in when the block
 // is handed out — the reference's scan over the returned frames (sound-processor.cc:116-125) happens once, on the device.
+//
+// An open file survives its GPU (round 5).  The reference can never emit silence from Process() (sound-processor.cc:98-127)
+// and moves a stream's state between owners at the gapless hand-over (convolve-file-handler.cc:328-351); on a node with
+// eight GPUs one of them failing must not end the files that were converting on it.  The state of a stream is its last K
+// input blocks (K partitions): a processor keeps the INPUT of every block it hands to the engine in a host ring of
+// K + run-ahead blocks (ordinary memory; one memcpy per block beside the two the file callbacks make anyway).  When an
+// engine call fails, the processor asks the DeviceRouter for another GPU, opens a stream of the same configuration there,
+// replays the kept K blocks through it (outputs discarded: that rebuilds the delay line), re-runs the failed call from
+// its kept input, and carries on there — same samples as if nothing had happened.  Silence is what is left only when no
+// other GPU can take the stream (or the ring would pass its memory budget: then nothing is kept).
 #pragma once
 
 #include <time.h>
@@ -76,6 +86,9 @@ public:
     // Where a run-ahead block's maxima come from: the GPU (K3 reduces every block; default) or a scan of the block on
     // the caller's thread when it is handed out (what the reference does, sound-processor.cc:116-125).
     static void SetDevicePeaks(bool on);
+    // Keep the input history that lets an open file move to another GPU when its own fails (default on; FOLVE_AMD_SURVIVE=0).
+    // Applies to processors created afterwards.
+    static void SetSurvival(bool on);
 private:
     static SoundProcessor* CreateOnReserved(fe_engine* engine, const std::string& config_file, int samplerate, int channels,
                                             bool* engine_fault);
@@ -119,7 +132,8 @@ public:
     int frames_wanted() const { return zita_config_.fragm - input_pos_; }   // what the reference's FillBuffer would ask its file for now
     int run_ahead() const { return run_depth_; }         // this processor's run-ahead depth in blocks
     fe_stream* stream() const { return stream_; }      // for batched submission
-    fe_engine* engine() const { return zita_config_.engine; }
+    fe_engine* engine() const { return engine_; }       // (changes when the processor has moved to another GPU)
+    int moves() const { return moves_; }                // times this processor's stream has moved to another GPU
     int device() const;
     bool ok() const { return ok_; }                     // false after an engine failure
 
@@ -134,23 +148,35 @@ private:
         void* request = nullptr;        // BatchScheduler::Request while on the GPU
         float* peaks = nullptr;         // [blocks][2]: every block's signed maximum and maximum magnitude, from the GPU
         bool peaks_valid = false;       // ... filled in (else the block is scanned when it is handed out)
+        long long first = 0;            // its first block, counted from the last Reset (the history ring's index)
     };
     SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth,
-                   const std::vector<std::pair<std::string, time_t>>& impulse_files);
+                   const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels);
     void Process();
     bool ReadChunk(FrameSource* in, Chunk* c);    // true if the chunk holds at least one whole block
     void SubmitChunk(Chunk* c);
-    void SettleChunk(Chunk* c);                   // wait for its request; on failure: silence, ok_ = false
+    void SettleChunk(Chunk* c);                   // wait for its request; on failure: the stream moves to another GPU (or silence, ok_ = false)
     void DrainRing();
     void ScanPeaks(const float* v, size_t n);
-    void EngineCallFailed();
     void EngineCallSucceeded();
+    // the input of `blocks` blocks (the last one `last_frames` long, the rest of it zeros) about to be handed to the engine
+    void KeepInput(const float* in, int blocks, int last_frames);
+    // The call for blocks [first, first + blocks) has failed: move to another GPU and produce its output there (`frames`
+    // frames into `out`).  False if nothing could take the stream: the caller falls back to silence.
+    bool MoveToAnotherGpu(long long first, int blocks, long long frames, float* out);
 
     const ZitaConfig zita_config_;
     const std::string config_file_;
     const time_t config_file_timestamp_;
     const std::vector<std::pair<std::string, time_t>> impulse_files_;   // what /impulse/read opened, and when it was last modified then
-    fe_stream* const stream_;
+    const int samplerate_, channels_;   // what Create was asked for (another GPU's filter is looked up by them)
+    fe_engine* engine_;                 // the GPU this processor's stream lives on: zita_config_.engine until a move
+    fe_stream* stream_;
+    float* hist_;                       // input history: hist_cap_ blocks of fragm * ninp floats, block b in slot b % hist_cap_ (NULL: none kept)
+    int hist_cap_;
+    int hist_k_;                        // the filter's partitions: blocks of history a stream's state consists of
+    long long blocks_fed_;              // blocks handed to the engine since the last Reset
+    int moves_;
 
     const int run_depth_;               // 1: no run-ahead
     const size_t buffer_floats_;
@@ -170,7 +196,7 @@ private:
     float max_out_value_observed_;
     float max_abs_value_observed_;
     bool ok_;
-    const std::atomic<int>* const slot_health_;   // the router's state of this processor's GPU slot (0: healthy)
+    const std::atomic<int>* slot_health_;         // the router's state of this processor's GPU slot (0: healthy)
 };
 
 }  // namespace folve

@@ -138,11 +138,13 @@ __global__ __launch_bounds__(256, (3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8
         };
         const float2* xrow = X + (size_t)ring_slot(job.slot0, tb, ring) * P;
         const float2* const xend = X + (size_t)ring * P;
-        // (past the tile's last block the walk keeps requesting the ring's next rows: always inside the stream's ring, whatever
-        // they hold is never used — and a clamp to the last row would cost five scalar instructions per step)
-        auto advance = [&]() {
+        int left = __builtin_amdgcn_readfirstlane(nb);      // blocks not yet requested (a scalar, and the compiler is told so)
+        auto advance = [&]() {                              // past the tile's last block: stay on it (re-read from L2, never used:
+            const bool more_rows = left > 1;                // D rows of HBM traffic per wavefront and call otherwise — 57 MB of cfg3's 4.6 GB)
             const float2* nx = xrow + P;
-            xrow = (nx == xend) ? X : nx;
+            nx = (nx == xend) ? X : nx;
+            xrow = more_rows ? nx : xrow;
+            left = max(left - 1, 1);
         };
         // the first even step's carry: the odd rows' products of T(0), all from the history
         v2f carry;

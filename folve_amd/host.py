@@ -31,6 +31,8 @@ HOST_SYMBOLS = [
     ("fh_router_cached_filters", _i, []),
     ("fh_processor_engine", _vp, [_vp]),
     ("fh_processor_ok", _i, [_vp]),
+    ("fh_processor_moves", _i, [_vp]),
+    ("fh_survival_set", None, [_i]),
     ("fh_pool_create", _vp, [_i]),
     ("fh_pool_destroy", None, [_vp]),
     ("fh_pool_get_or_create", _vp, [_vp, C.c_char_p, _i, _i, _i, C.c_char_p, _i]),

@@ -71,7 +71,13 @@ int fh_processor_config_still_up_to_date(const fh_processor *p);
 int fh_processor_device(const fh_processor *p);
 fe_stream *fh_processor_stream(const fh_processor *p);
 fe_engine *fh_processor_engine(const fh_processor *p);
-int fh_processor_ok(const fh_processor *p);            /* 0 after an engine failure (the pool discards it) */
+int fh_processor_ok(const fh_processor *p);            /* 0 once the processor has emitted silence: its GPU failed and no other could take the
+                                                          stream (the pool discards it) */
+int fh_processor_moves(const fh_processor *p);         /* times the processor's stream has moved to another GPU after its own failed: the
+                                                          processor keeps the input of its last K + run-ahead blocks, replays the K blocks of
+                                                          state on the new GPU and re-runs the failed call there (sound_processor.h) */
+void fh_survival_set(int on);                          /* keep that input history (default 1; 0: a GPU failure ends a file in silence, as until
+                                                          round 4); applies to processors created afterwards */
 
 /* processor-pool.cc:33 ProcessorPool(max_per_config) */
 fh_pool *fh_pool_create(int max_per_config);

@@ -102,19 +102,60 @@ def main():
     ok_before = sum(L.fh_processor_ok(p.h) for p in procs)
     states_before = [L.fh_router_slot_state(s) for s in range(NSLOT)]
 
-    # ---- one GPU goes bad --------------------------------------------------------------------------------------------
+    # ---- one GPU goes bad, in mid-conversion --------------------------------------------------------------------------
     BAD = 3
-    assert L.fe_engine_set_tuning(engines[BAD], capi.FE_TUNE_FAIL_NEXT, -1) == 0
     for p in procs:
         p.reset()
+    long_blocks = 96                                     # long enough that every file is still converting when the GPU dies
+    xl = [np.random.default_rng(200 + s).uniform(-1, 1, (long_blocks * 8192 + 500 + 11 * s, 2)).astype(np.float32) for s in range(8)]
+    on_bad = [i for i, p in enumerate(procs) if slot_of[int(L.fh_processor_engine(p.h))] == BAD]
+    outs_bad = {}
+    assert len(on_bad) == THREADS
+    others = [i for i in range(total) if i not in set(on_bad)]
+    gate = threading.Barrier(THREADS)
+    KILL_AT = 20                                         # blocks of its file every bad-slot processor has returned when the GPU dies
+
+    def run_long(t):
+        # this thread's file on the bad slot first — block by block (the AddMoreSoundData loop, convolve-file-handler.cc:370-424),
+        # so that all 64 of them are at block 20 of 96, chunks in flight, when the engine starts failing
+        i = on_bad[t]
+        p, x = procs[i], xl[i % 8]
+        outs, done, blocks = [], 0, 0
+        while done < x.shape[0]:
+            r = p.fill_buffer(x[done:])
+            assert r > 0
+            outs.append(p.write_processed(r))
+            done += r
+            blocks += 1
+            if blocks == KILL_AT and gate.wait() == 0:
+                assert L.fe_engine_set_tuning(engines[BAD], capi.FE_TUNE_FAIL_NEXT, -1) == 0
+        outs_bad[i] = np.concatenate(outs, 0)
+        # ... then its share of the other 448
+        for k in range(t * len(others) // THREADS, (t + 1) * len(others) // THREADS):
+            j = others[k]
+            y = procs[j].run(xl[j % 8])
+            if j % 41 == 0:
+                outs_bad[j] = y
+
     t0 = time.perf_counter()
-    threads(run_range, THREADS, procs, set())
+    threads(run_long, THREADS)
     t_run_bad = time.perf_counter() - t0
-    ok_after = [0] * NSLOT
-    for p in procs:
-        ok_after[slot_of[int(L.fh_processor_engine(p.h))]] += L.fh_processor_ok(p.h)
+    refl = {}
+    worst_bad, silent_blocks, peak_err = 0.0, 0, 0.0
+    for i, y in sorted(outs_bad.items()):
+        if i % 8 not in refl:
+            refl[i % 8] = f64_convolution(xl[i % 8], taps)
+        worst_bad = max(worst_bad, float(np.sqrt(np.mean((y.astype(np.float64) - refl[i % 8]) ** 2))))
+        nblk = y.shape[0] // 8192
+        silent_blocks += int(sum(not y[b * 8192:(b + 1) * 8192].any() for b in range(nblk)))
+        peak_err = max(peak_err, abs(procs[i].max_output_value() - max(0.0, float(y.max()))))
+    moves = [L.fh_processor_moves(procs[i].h) for i in on_bad]
+    moved_mid = sum(1 for i in on_bad if L.fh_processor_moves(procs[i].h) >= 1)
+    still_on_bad = sum(1 for p in procs if int(L.fh_processor_engine(p.h)) == engines[BAD])
+    ok_after = sum(L.fh_processor_ok(p.h) for p in procs)
     states_bad = [L.fh_router_slot_state(s) for s in range(NSLOT)]
     failures_bad = L.fh_router_slot_failures(BAD)
+    live_after_move = [L.fh_router_live_streams(s) for s in range(NSLOT)]
     # new files while it is fenced: never NULL, never there
     more = [None] * 56
     threads(lambda t: open_range(t * 7, (t + 1) * 7, more), 8)
@@ -123,7 +164,7 @@ def main():
     live_more = [L.fh_router_live_streams(s) for s in range(NSLOT)]
     y = more[0].run(xs[0])
     rms_more = float(np.sqrt(np.mean((y.astype(np.float64) - refs.setdefault(0, f64_convolution(xs[0], taps))) ** 2)))
-    # everything back to the pool: only the bad slot's processors are discarded
+    # everything back to the pool: nothing lives on the bad slot any more, nothing is discarded
     for p in procs + more:
         pool.give_back(p)
     pooled = pool.pooled_count(conf)
@@ -155,7 +196,9 @@ def main():
            "run_ahead": depth, "open_s": round(t_open, 2), "run_s": round(t_run, 2), "run_bad_s": round(t_run_bad, 2),
            "msamples_per_s": round(total * (blocks * 8192) * 2 / t_run / 1e6, 1),
            "checked": len(outs), "max_rms": worst, "ok_before": ok_before, "states_before": states_before,
-           "ok_after_per_slot": ok_after, "states_bad": states_bad, "failures_bad": failures_bad,
+           "ok_after": ok_after, "states_bad": states_bad, "failures_bad": failures_bad, "files_on_bad": len(on_bad),
+           "moved": moved_mid, "max_moves": max(moves) if moves else 0, "still_on_bad": still_on_bad, "checked_bad_phase": len(outs_bad),
+           "max_rms_bad_phase": worst_bad, "silent_blocks": silent_blocks, "peak_err": peak_err, "live_after_move": live_after_move,
            "more_null": more_null, "more_on_bad": more_on_bad, "live_more": live_more, "rms_more": rms_more,
            "pooled": pooled, "live_pooled": live_pooled, "again_on_bad": again_on_bad, "pooled_cfg": pooled_cfg,
            "state_back": state_back, "back_on_bad": back_on_bad, "rms_back": rms_back,

@@ -36,9 +36,9 @@ def test_two_router_slots_share_the_load(tmp_path):
 def test_cfg5_shape_eight_slots_512_streams_and_one_gpu_going_bad(tmp_path):
     """BASELINE.json configs[4] on one device: eight router slots, 512 SoundProcessors of cfg3's filter opened through
     ProcessorPool from 64 threads (64 per slot exactly), all 512 converting at once with spot parity against float64;
-    then one slot's engine fails every call: its files fail and say so, the slot is fenced, the next opens land on the
-    other seven and none returns NULL, the pool discards that slot's processors only; when the engine works again a
-    probe puts the slot back in service.  (tests/cfg5_worker.py; /root/reference/processor-pool.cc:48-91)"""
+    then one slot's engine starts failing every call while its 64 files are in mid-conversion: they move to the other
+    slots from their kept input and come out equal to the float64 convolution, the slot is fenced, the next opens land on
+    the other seven and none returns NULL; when the engine works again a probe puts the slot back in service.  (tests/cfg5_worker.py; /root/reference/processor-pool.cc:48-91)"""
     env = dict(os.environ, FOLVE_AMD_DEVICES="0,0,0,0,0,0,0,0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cfg5_worker.py"), str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=1200)
@@ -50,12 +50,16 @@ def test_cfg5_shape_eight_slots_512_streams_and_one_gpu_going_bad(tmp_path):
     assert out["cached_filters"] == 8                                            # one committed filter per slot
     assert out["checked"] >= 12 and out["max_rms"] <= 1e-5
     assert out["ok_before"] == 512 and out["states_before"] == [0] * 8
-    # one GPU bad: exactly its 64 files failed, the slot is fenced, the others never noticed
-    assert out["ok_after_per_slot"] == [0 if s == bad else 64 for s in range(8)]
+    # one GPU goes bad in mid-conversion: its 64 files MOVE to the other slots and come out right — every one of them checked
+    # against float64, peaks included, no block of silence; the slot is fenced, the others never noticed
+    assert out["files_on_bad"] == 64 and out["moved"] == 64 and out["max_moves"] == 1 and out["still_on_bad"] == 0
+    assert out["ok_after"] == 512
+    assert out["checked_bad_phase"] >= 64 and out["max_rms_bad_phase"] <= 1e-5 and out["silent_blocks"] == 0 and out["peak_err"] <= 1e-6
+    assert out["live_after_move"][bad] == 0 and sum(out["live_after_move"]) == 512
     assert out["states_bad"] == [2 if s == bad else 0 for s in range(8)] and out["failures_bad"] >= 3
     assert out["more_null"] == 0 and out["more_on_bad"] == 0 and out["rms_more"] <= 1e-5
-    assert out["live_more"] == [64 if s == bad else 72 for s in range(8)]
-    assert out["pooled"] == 512 + 56 - 64 and out["live_pooled"][bad] == 0       # only the bad slot's processors were discarded
+    assert out["live_more"][bad] == 0 and sum(out["live_more"]) == 512 + 56
+    assert out["pooled"] == 512 + 56 and out["live_pooled"][bad] == 0            # nothing was lost: every processor went back to the pool
     assert out["again_on_bad"] == 0
     # and back in service
     assert out["state_back"] == 0 and out["back_on_bad"] == 8 and out["rms_back"] <= 1e-5

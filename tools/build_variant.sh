@@ -11,5 +11,5 @@ for k in kernels mac_walk3; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o folve_amd/variants/libfolve_amd_$name.so /tmp/fkv_$name/kernels.o /tmp/fkv_$name/mac_walk3.o \
-    $(find folve_amd/csrc/build -name '*.o' ! -name kernels.o ! -name mac_walk3.o) -lpthread
+    $(find folve_amd/csrc/build -name '*.o' ! -name kernels.o ! -name mac_walk3.o) -lpthread -ldl
 echo built folve_amd/variants/libfolve_amd_$name.so

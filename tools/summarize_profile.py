@@ -19,7 +19,7 @@ res = {"kernel_trace": {}, "kernel_stats": {}, "pmc": {}}
 
 def short(name):
     for k in ("forward_dual_kernel", "make_g_kernel", "forward_walker_kernel", "inverse_walker_kernel", "forward_chpair_kernel",
-              "inverse_chpair_kernel", "forward_pair_kernel", "inverse_pair_kernel", "mac_slide_kernel", "mac_walk_kernel",
+              "inverse_chpair_kernel", "forward_pair_kernel", "inverse_pair_kernel", "mac_slide_kernel", "mac_walk3_kernel", "mac_walk_kernel",
               "mac_small_kernel", "forward_kernel", "mac_kernel", "inverse_kernel", "filter_kernel"):
         if k in name:
             t = name.split(k)[1].split(">")[0].strip("<")
