@@ -137,7 +137,7 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     int run_depth = RunAheadForBlock(zita.fragm);
     {
         const size_t in = static_cast<size_t>(zita.fragm) * zita.ninp, out = static_cast<size_t>(zita.fragm) * zita.nout;
-        const size_t block_bytes = (zita.ninp == zita.nout ? in : in + out) * sizeof(float);     // (ChunkFloats, below)
+        const size_t block_bytes = (zita.ninp == zita.nout && !SurvivalWanted() ? in : in + out) * sizeof(float);     // (ChunkFloats, below)
         const size_t fit = block_bytes ? kRingBudgetBytes / (2 * block_bytes) : static_cast<size_t>(run_depth);
         if (fit < static_cast<size_t>(run_depth)) run_depth = static_cast<int>(std::max<size_t>(fit, 1));
     }
@@ -172,12 +172,14 @@ static float* AllocBlockBuffer(size_t floats, bool* pinned) {
     return new float[floats];
 }
 
-// Floats of one run-ahead chunk: `depth` blocks of input and of output; in place when the channel counts agree
-// (folve_engine.h: in-place calls of any length are fine then).
-static size_t ChunkFloats(const ZitaConfig& c, int depth) {
+// Floats of one run-ahead chunk: `depth` blocks of input and of output.  In place when the channel counts agree and no
+// input history is kept (folve_engine.h: in-place calls of any length are fine then); with the history (the default) a
+// chunk's input must outlive its call — it is what a move to another GPU re-runs and replays — so the output has its own
+// half and nothing has to be copied aside.
+static size_t ChunkFloats(const ZitaConfig& c, int depth, bool in_place) {
     if (depth <= 1) return 0;
     const size_t in = static_cast<size_t>(depth) * c.fragm * c.ninp, out = static_cast<size_t>(depth) * c.fragm * c.nout;
-    return c.ninp == c.nout ? in : in + out;
+    return in_place ? in : in + out;
 }
 
 SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream, int run_depth,
@@ -186,8 +188,9 @@ SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg,
       samplerate_(samplerate), channels_(channels), engine_(config.engine),
       stream_(stream), hist_(NULL), hist_cap_(0), hist_k_(0), blocks_fed_(0), moves_(0),
       run_depth_(run_depth),
+      in_place_(config.ninp == config.nout && !SurvivalWanted()),
       buffer_floats_(static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)),
-      arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth)),
+      arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth, config.ninp == config.nout && !SurvivalWanted())),
       buffer_(AllocBlockBuffer(arena_floats_, &buffer_pinned_)),
       cur_(NULL), ahead_(NULL), ring_block_(NULL), tail_(NULL), tail_frames_(0), source_short_(false), depth_next_(1),
       input_pos_(0), output_pos_(0), max_out_value_observed_(0.0), max_abs_value_observed_(0.0), ok_(true),
@@ -201,20 +204,26 @@ SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg,
         const size_t in = static_cast<size_t>(run_depth_) * config.fragm * config.ninp;
         for (Chunk& c : chunks_) {
             c.in = p;
-            c.out = config.ninp == config.nout ? p : p + in;
-            p += ChunkFloats(config, run_depth_);
+            c.out = in_place_ ? p : p + in;
+            p += ChunkFloats(config, run_depth_, in_place_);
         }
         tail_ = new float[static_cast<size_t>(config.fragm) * config.ninp];
         for (Chunk& c : chunks_) c.peaks = new float[2 * static_cast<size_t>(run_depth_)];
     }
-    // the input history an open file needs to move to another GPU: K blocks of state + the longest call's own input
+    // The input history an open file needs to move to another GPU (sound_processor.h): the K blocks in front of a call and
+    // the call's own input.  A run-ahead chunk's input stays where it is (its output has its own half of the chunk), so the
+    // ring only ever takes what would otherwise be overwritten while still needed: single blocks (computed in place), chunks
+    // shorter than K (the ramp, a file's end) and the tail of a long chunk whose buffer is about to be re-used early.
     if (SurvivalWanted()) {
         hist_k_ = config.fragm > 0 ? static_cast<int>((static_cast<long long>(config.size) + config.fragm - 1) / config.fragm) : 0;
-        const long long cap = static_cast<long long>(hist_k_) + std::max(run_depth_, 1);
+        const long long cap = 2LL * hist_k_ + 2;
         const size_t bytes = static_cast<size_t>(cap) * config.fragm * config.ninp * sizeof(float);
         if (hist_k_ > 0 && bytes <= kRingBudgetBytes) {
             hist_ = new (std::nothrow) float[bytes / sizeof(float)];
-            if (hist_) hist_cap_ = static_cast<int>(cap);
+            if (hist_) {
+                hist_cap_ = static_cast<int>(cap);
+                hist_tag_.assign(static_cast<size_t>(cap), -1);
+            }
         }
         if (!hist_) Logf("Processor %p: no input history kept (%zu bytes): a GPU failure under it ends in silence", static_cast<void*>(this), bytes);
     }
@@ -246,6 +255,15 @@ void SoundProcessor::EngineCallSucceeded() {
 // read-ahead until everything read so far has been handed out.
 bool SoundProcessor::ReadChunk(FrameSource* in, Chunk* c) {
     const int P = zita_config_.fragm;
+    if (c->holds) {
+        // This buffer still holds the input of an earlier chunk.  Whatever of it lies among the last K blocks handed to the
+        // engine is state a later call may have to replay: it goes to the ring before the buffer is re-used.  (Long chunks
+        // alternating — the steady state — find nothing here: the K most recent blocks are all in the OTHER buffer.)
+        const long long lo = std::max(c->first, blocks_fed_ - hist_k_), hi = c->first + c->blocks;
+        if (hist_ && lo < hi && c->blocks >= hist_k_)             // (a shorter chunk was saved when it was submitted)
+            SaveBlocks(c->in + static_cast<size_t>(lo - c->first) * P * input_channels(), lo, static_cast<int>(hi - lo), P);
+        c->holds = false;
+    }
     const int want = depth_next_ * P;
     const int got = in->ReadFrames(c->in, want);
     c->blocks = got / P;
@@ -266,7 +284,9 @@ void SoundProcessor::SubmitChunk(Chunk* c) {
     const long long frames = static_cast<long long>(c->blocks) * zita_config_.fragm;
     c->peaks_valid = false;
     c->first = blocks_fed_;
-    KeepInput(c->in, c->blocks, zita_config_.fragm);        // (the call may overwrite its input in place)
+    c->holds = hist_ != NULL;                                // (its input stays in place: the output has its own half of the chunk)
+    if (hist_ && c->blocks < hist_k_) SaveBlocks(c->in, c->first, c->blocks, zita_config_.fragm);   // short: the next chunks may overwrite it while it still counts
+    blocks_fed_ += c->blocks;
     if (ftrace::events_on()) ftrace::event("submit processor=%p gpu=%d first_block=%lld blocks=%d", static_cast<void*>(this), device(), c->first, c->blocks);
     if (BatchScheduler::Enabled()) {
         c->request = BatchScheduler::ForEngine(engine_)->Submit(stream_, c->in, frames, c->out,
@@ -308,34 +328,58 @@ void SoundProcessor::SettleChunk(Chunk* c) {
     }
 }
 
-// The input of blocks about to go to the engine, into the history ring (block b in slot b % hist_cap_); a short last
-// block is padded with the zeros the engine assumes behind it.
-void SoundProcessor::KeepInput(const float* in, int blocks, int last_frames) {
+// `n` blocks of input (block numbers b0 ..; the last one `last_frames` long, padded with the zeros the engine assumes behind
+// it) into the history ring: block b in slot b % hist_cap_, tagged with its number.
+void SoundProcessor::SaveBlocks(const float* in, long long b0, int n, int last_frames) {
     const size_t bf = static_cast<size_t>(zita_config_.fragm) * input_channels();
-    if (hist_) {
-        for (int b = 0; b < blocks; ++b) {
-            float* dst = hist_ + static_cast<size_t>((blocks_fed_ + b) % hist_cap_) * bf;
-            const size_t n = (b == blocks - 1 ? static_cast<size_t>(last_frames) : static_cast<size_t>(zita_config_.fragm)) * input_channels();
-            memcpy(dst, in + static_cast<size_t>(b) * bf, n * sizeof(float));
-            if (n < bf) memset(dst + n, 0, (bf - n) * sizeof(float));
-        }
+    for (int b = 0; b < n; ++b) {
+        const size_t slot = static_cast<size_t>((b0 + b) % hist_cap_);
+        float* dst = hist_ + slot * bf;
+        const size_t k = (b == n - 1 ? static_cast<size_t>(last_frames) : static_cast<size_t>(zita_config_.fragm)) * input_channels();
+        memcpy(dst, in + static_cast<size_t>(b) * bf, k * sizeof(float));
+        if (k < bf) memset(dst + k, 0, (bf - k) * sizeof(float));
+        hist_tag_[slot] = b0 + b;
     }
+}
+
+// A single block about to be computed in place (Process()): its input goes to the ring.
+void SoundProcessor::KeepInput(const float* in, int blocks, int last_frames) {
+    if (hist_) SaveBlocks(in, blocks_fed_, blocks, last_frames);
     blocks_fed_ += blocks;
 }
 
-// See the head of sound_processor.h.  The history ring holds blocks [blocks_fed_ - hist_cap_, blocks_fed_); the failed
-// call's blocks are its newest `blocks`, the state in front of them the hist_k_ blocks before.
+// Where block b's input is now: in a chunk buffer that still holds it, or in the ring; NULL if it is gone.
+const float* SoundProcessor::BlockInput(long long b) const {
+    const size_t bf = static_cast<size_t>(zita_config_.fragm) * input_channels();
+    for (const Chunk& c : chunks_)
+        if (c.holds && b >= c.first && b < c.first + c.blocks) return c.in + static_cast<size_t>(b - c.first) * bf;
+    if (hist_ && b >= 0) {
+        const size_t slot = static_cast<size_t>(b % hist_cap_);
+        if (hist_tag_[slot] == b) return hist_ + slot * bf;
+    }
+    return NULL;
+}
+
+// See the head of sound_processor.h.  The failed call's blocks are the newest `blocks` handed to the engine, the state in
+// front of them the hist_k_ blocks before.
 bool SoundProcessor::MoveToAnotherGpu(long long first, int blocks, long long frames, float* out) {
-    if (!hist_ || blocks <= 0 || blocks + hist_k_ > hist_cap_ || first + blocks != blocks_fed_) return false;
+    if (!hist_ || blocks <= 0 || first + blocks != blocks_fed_) return false;
     DeviceRouter* router = DeviceRouter::Default();
     const int P = zita_config_.fragm;
     const size_t bf = static_cast<size_t>(P) * input_channels();
     const long long replay0 = std::max<long long>(0, first - hist_k_);
     const long long nrep = first - replay0;
-    // the kept blocks in order, contiguous (the ring wraps): [replay | the failed call's own input]
+    // the kept blocks in order, contiguous: [replay | the failed call's own input]  (a copy: the call's output may share
+    // memory with its input — Process() computes in place)
     std::vector<float> in(static_cast<size_t>(nrep + blocks) * bf);
-    for (long long b = replay0; b < first + blocks; ++b)
-        memcpy(in.data() + static_cast<size_t>(b - replay0) * bf, hist_ + static_cast<size_t>(b % hist_cap_) * bf, bf * sizeof(float));
+    for (long long b = replay0; b < first + blocks; ++b) {
+        const float* src = BlockInput(b);
+        if (!src) {
+            Logf("Processor %p: block %lld of its input history is gone: the stream cannot move", static_cast<void*>(this), b);
+            return false;
+        }
+        memcpy(in.data() + static_cast<size_t>(b - replay0) * bf, src, bf * sizeof(float));
+    }
     std::vector<float> scratch(static_cast<size_t>(std::max<long long>(nrep, 1)) * P * output_channels());
     std::vector<fe_engine*> tried(1, engine_);
     for (;;) {
@@ -388,6 +432,7 @@ void SoundProcessor::DrainRing() {
     for (Chunk& c : chunks_) {
         SettleChunk(&c);
         c.blocks = c.next = 0;
+        c.holds = false;
     }
     cur_ = ahead_ = NULL;
     ring_block_ = NULL;
@@ -535,6 +580,7 @@ void SoundProcessor::Reset() {
     DrainRing();
     fe_stream_reset(stream_);
     blocks_fed_ = 0;                     // (a reset stream has no state: nothing before this point would be replayed)
+    std::fill(hist_tag_.begin(), hist_tag_.end(), -1LL);
     input_pos_ = 0;
     output_pos_ = -1;
     ResetMaxValues();

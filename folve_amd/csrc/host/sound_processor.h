@@ -31,8 +31,11 @@
 // An open file survives its GPU (round 5).  The reference can never emit silence from Process() (sound-processor.cc:98-127)
 // and moves a stream's state between owners at the gapless hand-over (convolve-file-handler.cc:328-351); on a node with
 // eight GPUs one of them failing must not end the files that were converting on it.  The state of a stream is its last K
-// input blocks (K partitions): a processor keeps the INPUT of every block it hands to the engine in a host ring of
-// K + run-ahead blocks (ordinary memory; one memcpy per block beside the two the file callbacks make anyway).  When an
+// input blocks (K partitions).  A run-ahead chunk's input simply stays where it was read to — its output has its own half
+// of the chunk — until that buffer is read into again two chunks later; what would be overwritten while it still counts
+// (single blocks, which are computed in place; chunks shorter than K: the ramp, a file's end; the tail of a long chunk
+// whose buffer is re-used early) goes to a host ring of 2 K + 2 blocks first.  In the steady state of long chunks nothing
+// is copied at all.  When an
 // engine call fails, the processor asks the DeviceRouter for another GPU, opens a stream of the same configuration there,
 // replays the kept K blocks through it (outputs discarded: that rebuilds the delay line), re-runs the failed call from
 // its kept input, and carries on there — same samples as if nothing had happened.  Silence is what is left only when no
@@ -149,6 +152,7 @@ private:
         float* peaks = nullptr;         // [blocks][2]: every block's signed maximum and maximum magnitude, from the GPU
         bool peaks_valid = false;       // ... filled in (else the block is scanned when it is handed out)
         long long first = 0;            // its first block, counted from the last Reset (the history ring's index)
+        bool holds = false;             // in[] still holds the input of blocks [first, first + blocks) (it has not been read into since)
     };
     SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth,
                    const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels);
@@ -161,6 +165,8 @@ private:
     void EngineCallSucceeded();
     // the input of `blocks` blocks (the last one `last_frames` long, the rest of it zeros) about to be handed to the engine
     void KeepInput(const float* in, int blocks, int last_frames);
+    void SaveBlocks(const float* in, long long b0, int n, int last_frames);
+    const float* BlockInput(long long b) const;
     // The call for blocks [first, first + blocks) has failed: move to another GPU and produce its output there (`frames`
     // frames into `out`).  False if nothing could take the stream: the caller falls back to silence.
     bool MoveToAnotherGpu(long long first, int blocks, long long frames, float* out);
@@ -172,13 +178,15 @@ private:
     const int samplerate_, channels_;   // what Create was asked for (another GPU's filter is looked up by them)
     fe_engine* engine_;                 // the GPU this processor's stream lives on: zita_config_.engine until a move
     fe_stream* stream_;
-    float* hist_;                       // input history: hist_cap_ blocks of fragm * ninp floats, block b in slot b % hist_cap_ (NULL: none kept)
+    float* hist_;                       // input history: hist_cap_ = 2 K + 2 blocks of fragm * ninp floats, block b in slot b % hist_cap_ (NULL: none kept)
+    std::vector<long long> hist_tag_;   // the block number each slot holds (-1: none)
     int hist_cap_;
     int hist_k_;                        // the filter's partitions: blocks of history a stream's state consists of
     long long blocks_fed_;              // blocks handed to the engine since the last Reset
     int moves_;
 
     const int run_depth_;               // 1: no run-ahead
+    const bool in_place_;               // run-ahead chunks are computed in place (only without the input history)
     const size_t buffer_floats_;
     const size_t arena_floats_;         // block buffer + both chunks, one page-locked allocation
     bool buffer_pinned_;

@@ -477,19 +477,35 @@ int survive_scenario(const std::string& dir) {
             folve::SoundProcessor* p = procs[t];
             const int dev0 = p->device();
             std::mt19937 rng((unsigned)(t * 31 + rd.depth));
-            const size_t n = (size_t)(14 + t) * P + 1 + rng() % (P - 1);     // 14 .. 21 blocks and a short last one
-            std::vector<float> a(n * 2);
+            // even threads: one file; odd threads: two files handed over gaplessly (convolve-file-handler.cc:328-351) with the
+            // GPUs dying two blocks into the SECOND file — the state to replay then spans the first file's last long chunk
+            // (saved from its buffer just before the second file's first chunk is read into it), its short last chunk and the
+            // topped-up block in between
+            const bool two = (t & 1) != 0;
+            const size_t na = (size_t)(14 + t) * P + 1 + rng() % (P - 1);     // 14 .. 21 blocks and a short last one
+            const size_t nb2 = two ? (size_t)9 * P + 1 + rng() % (P - 1) : 0;
+            std::vector<float> a((na + nb2) * 2);
             for (auto& v : a) v = (float)(rng() % 2001) / 1000.f - 1.f;
-            MemSource src(&a, 2);
+            std::vector<float> fa(a.begin(), a.begin() + (long)na * 2), fb(a.begin() + (long)na * 2, a.end());
+            MemSource sa(&fa, 2), sb(&fb, 2);
+            MemSource* srcs[2] = {&sa, &sb};
+            const int nsrc = two ? 2 : 1;
+            const int at = two ? (int)(na / P) + 3 : rd.at;
+            const size_t n = na + nb2;
             MemSink out(2);
             long long left = (long long)n;
-            int blocks = 0;
+            int blocks = 0, si = 0;
             while (left) {
-                const int got = p->FillBuffer(&src);
-                if (got <= 0) break;
+                int got = p->FillBuffer(srcs[si]);
+                if (got <= 0) { if (++si >= nsrc) break; continue; }
                 left -= got;
+                if (!p->is_input_buffer_complete() && si + 1 < nsrc && srcs[si]->pos * 2 == srcs[si]->d->size()) {
+                    const int more = p->FillBuffer(srcs[++si]);                // the next file tops the block up
+                    got += more;
+                    left -= more;
+                }
                 p->WriteProcessed(&out, got);
-                if (++blocks == rd.at) {                                 // every file is in mid-conversion: now the GPUs die
+                if (++blocks == at) {                                    // every file is in mid-conversion: now the GPUs die
                     if (reached.fetch_add(1) + 1 == (int)procs.size())
                         for (int d : rd.kill) g_dead[d] = 1;
                     while (reached.load() < (int)procs.size()) std::this_thread::yield();

@@ -507,8 +507,18 @@ def test_host_layer_on_a_fake_engine_under_sanitizers(tmp_path, sanitizer):
     # an open file survives its GPU (sound_processor.h): GPUs dying under files in mid-conversion — the files move to other
     # GPUs from their kept input and come out as if nothing had happened; silence only when no GPU is left
     # (the reference never drops a block, sound-processor.cc:98-127; state moves between owners, convolve-file-handler.cc:328-351)
+    trace = os.path.join(str(tmp_path), "events.txt")
     r = subprocess.run([exe, work, "survive"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1"))
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1",
+                                FOLVE_AMD_TRACE=trace))
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
     assert json.loads(r.stdout.strip().splitlines()[-1]) == {"survive_scenario": "ok", "failed_checks": 0}
+    # ... and the host-layer event log of that run (FOLVE_AMD_TRACE, csrc/trace.h: the counterpart of folve's -D,
+    # /root/reference/folve-main.cc:63-97): "<us> <tid> <event> ...", the moves among the chunk submits and settles
+    ev = [l.split(None, 3) for l in open(trace).read().splitlines()]
+    assert ev and all(len(e) >= 3 and e[0].isdigit() and e[1].isdigit() for e in ev)
+    kinds = {e[2] for e in ev}
+    assert {"submit", "settle", "move"} <= kinds, kinds
+    assert sum(e[2] == "move" for e in ev) >= 7                    # rounds 1 - 4: 1 + 1 + 2 + 3 GPUs died, each under one or two files
+    assert len({e[1] for e in ev}) >= 8                             # eight file threads

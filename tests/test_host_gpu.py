@@ -536,3 +536,36 @@ def test_router_health_on_the_only_gpu(oracle, tmp_path):
     ref[dl:] += 0.3 * x[:-dl].astype(np.float64)
     assert oracle.rms(y - ref) <= TOL
     pool.give_back(q)
+
+
+def test_roctx_ranges_and_the_host_event_log(tmp_path):
+    """The tracing hooks (csrc/trace.h): with FOLVE_AMD_ROCTX=1 every launch round is a roctxRangePush / Pop
+    pair on the real roctx library (looked up at run time) and with FOLVE_AMD_TRACE the host layer logs pool and chunk events —
+    the counterpart of folve's -D (/root/reference/folve-main.cc:63-97).  A fresh process (both switches are read once); the
+    convolution under them must be what it is without."""
+    import subprocess
+    import sys
+    d = make_echo_filter_dir(tmp_path)
+    dl = int(golden("echo")["delay_44100"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = os.path.join(str(tmp_path), "events.txt")
+    code = (
+        "import sys, os, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import folve_amd.host as H\n"
+        "pool = H.ProcessorPool(3)\n"
+        "p, err = pool.get_or_create(%r, 44100, 2, 16)\n"
+        "assert p is not None, err\n"
+        "x = np.random.default_rng(5).uniform(-1, 1, (40 * 8192 + 100, 2)).astype(np.float32)\n"
+        "y = p.run(x)\n"
+        "ref = 0.7 * x.astype(np.float64); ref[%d:] += 0.3 * x[:-%d]\n"
+        "print('RMS', float(np.sqrt(np.mean((y - ref) ** 2))))\n"
+        "pool.give_back(p)\n" % (root, d, dl, dl))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, FOLVE_AMD_ROCTX="1", FOLVE_AMD_TRACE=log))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "no roctx library could be loaded" not in r.stderr, r.stderr[-1000:]
+    assert float([l for l in r.stdout.splitlines() if l.startswith("RMS")][-1].split()[1]) <= TOL
+    ev = [l.split(None, 3) for l in open(log).read().splitlines()]
+    kinds = [e[2] for e in ev]
+    assert kinds[0] == "GetOrCreate" and kinds[-1] == "Return" and "submit" in kinds and "settle" in kinds

@@ -195,8 +195,9 @@ def test_run_ahead_with_unequal_channel_counts_and_small_blocks(oracle, tmp_path
 
 
 def test_many_channels_run_ahead_by_fewer_blocks(oracle, tmp_path, depth):
-    """A processor pins at most 64 MB for its two chunks: a block of a 32-channel stream at P = 8192 is 1 MB, so the
-    depth asked for (64) becomes 32; the block machine's results do not know (dirac paths: closed form)."""
+    """A processor pins at most 64 MB for its two chunks: a block of a 32-channel stream at P = 8192 is 1 MB of input and 1 MB
+    of output (a chunk's output has its own half since round 5: the input stays, for a move to another GPU), so the depth asked
+    for (64) becomes 16; the block machine's results do not know (dirac paths: closed form)."""
     conf = os.path.join(str(tmp_path), "filter-44100.conf")
     with open(conf, "w") as f:
         f.write("/convolver/new 32 32 256 20000\n")
@@ -205,7 +206,7 @@ def test_many_channels_run_ahead_by_fewer_blocks(oracle, tmp_path, depth):
     depth(64)
     sp = H.SoundProcessor.create(conf, 44100, 32)
     assert (sp.ninp, sp.nout, sp.fragm) == (32, 32, 8192)
-    assert sp.run_ahead() == 32
+    assert sp.run_ahead() == 16
     x = seeded_input(5, 37 * 8192 + 1234, 32)
     y = sp.run(x)
     exp = np.zeros_like(x, dtype=np.float64)

@@ -32,7 +32,9 @@ with open(out + "/markers.txt", "w") as w:
             w.write("%10.1f %8.1f %s %s\n" % ((int(r[start]) - t0) / 1e3, (int(r[end]) - int(r[start])) / 1e3, r.get("Thread_Id", r.get("Tid", "")), r[name]))
     by = collections.defaultdict(list)
     for r in kn:
-        by[r["Kernel_Name"].split("(")[0].split("::")[-1]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        import re
+        m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
+        by[m.group(1) if m else r["Kernel_Name"][:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     w.write("\nkernels (dispatches, average us):\n")
     for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         w.write("%-60s %6d %9.1f\n" % (k[:60], len(v), sum(v) / len(v) / 1e3))
