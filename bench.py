@@ -441,14 +441,14 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, lon
     if by and not ok:
         by = {}
     path_bytes = sum(by.values()) if len(by) == 3 else None
-    # A launch of a few tens of microseconds: the engine's HIP events stand one dependent-launch boundary apart, so an
+    # A launch of up to ~150 us: the engine's HIP events stand one dependent-launch boundary (3 - 7 us) apart, so an
     # event-to-event time holds the kernel AND the gap behind it (the three of them can add up to more than the call's wall
     # time).  Where the committed profile is of these very kernels, such a launch's duration is the profile's kernel-trace
     # average (`trace_us`), printed beside the event time, and `frac` divides by that.
     trace = entry.get("avg_ns") or {}
     kernels = {}
     for k in kms:
-        short = by.get(k) and trace.get(k) and kms[k] < 0.05
+        short = by.get(k) and trace.get(k) and kms[k] < 0.15
         t_ms = trace[k] / 1e6 if short else kms[k]
         kernels[k] = {"ms": round(t_ms, 4), "event_ms": round(kms[k], 4),
                       "trace_us": round(trace[k] / 1e3, 2) if (by.get(k) and trace.get(k)) else None,
