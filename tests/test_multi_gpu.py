@@ -105,6 +105,28 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert out["parity_rms"] <= 1e-5
 
 
+def test_bench_cfg5_shape_eight_ranks_512_streams_on_one_gpu():
+    """BASELINE.json configs[4] through bench.py itself: `python bench.py --gpus 8` — eight ranks x 64 streams x 256 blocks,
+    cfg5's 512 streams sharded gpu = stream mod 8 — with all eight ranks on device 0 over gloo (a one-GPU box: the rate it
+    prints is eight processes sharing one GPU and means nothing; what is checked is the launch, the sharding, the parity
+    gate on every rank at the full per-GPU shape, the barriers and reductions, and the line's completeness)."""
+    env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["streams_per_gpu"] == 64 and out["config"]["total_streams"] == 512 and out["config"]["blocks_per_step"] == 256
+    assert len(out["shards"]) == 8 and all(len(s) == 64 for s in out["shards"])
+    assert sorted(i for s in out["shards"] for i in s) == list(range(512)) and out["shards"][3][:3] == [3, 11, 19]
+    assert out["process_group"] == {"backend": "gloo", "world_size": 8, "forced_at_world_size_1": False}
+    assert out["parity_rms"] <= 1e-5 and out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+
+
 def test_bench_rccl_branch_runs_on_one_gpu():
     """The RCCL branch of bench.py — init_process_group("nccl", device_id), the barriers around the timed region and the
     reductions of sharding.aggregate_throughput, beside the engine's private HIP streams — behind FOLVE_BENCH_FORCE_DIST=1
