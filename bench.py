@@ -634,6 +634,13 @@ def main():
     # one-GPU box (all ranks on one device, gloo); the driver's runs use one rank per GPU over RCCL.
     dev = int(os.environ.get("FOLVE_BENCH_DEVICE", local_rank if world > 1 else 0))
     backend = os.environ.get("FOLVE_BENCH_BACKEND", "nccl")
+    if dev >= torch.cuda.device_count():
+        # (one rank per GPU: `--gpus N` needs N visible devices — or FOLVE_BENCH_DEVICE to put every rank on one, as the tests do)
+        sys.stderr.write("bench.py: rank %d wants GPU %d but only %d are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n"
+                         % (rank, dev, torch.cuda.device_count()))
+        if rank == 0:
+            print(json.dumps({"error": "rank %d wants GPU %d, %d visible" % (rank, dev, torch.cuda.device_count()), "n_gpus": world}))
+        sys.exit(2)
     torch.cuda.set_device(dev)
     dist = None
     # FOLVE_BENCH_FORCE_DIST=1: a process group even at world size 1, so that the RCCL branch below (init, barrier, the
