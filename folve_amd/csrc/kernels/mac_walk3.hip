@@ -59,7 +59,11 @@ __device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool he
 }
 
 template <int KR, int D, bool PIN, int LPB = 1, int NP = 1>
-__global__ __launch_bounds__(256, (3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8 : 0) <= 168) ? 3 : 2) void mac_walk3_kernel(
+#ifndef FOLVE_W3_WG
+#define FOLVE_W3_WG 256          // threads per workgroup (the walk uses neither LDS nor barriers: the size only shapes dispatch and DRAM
+                                 // locality).  Measured (-DFOLVE_W3_WG=512, tools/build_variant.sh): cfg3's K2 0.93 -> 1.02 ms, cfg4 the same
+#endif
+__global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8 : 0) <= 168) ? 3 : 2) * 256 / FOLVE_W3_WG) void mac_walk3_kernel(
     JobRef jr, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
     constexpr int W = KR + D;
     constexpr int KRP = (KR + 1) / 2;                       // pairs of rows
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, (3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8
 
 template <int KR, int D, int LPB, int NP = 1>
 hipError_t launch3(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, const Tuning& tn, hipStream_t st) {
-    dim3 grid(f.P * LPB / 256, f.cout * w.tiles, njobs), block(256);
+    dim3 grid(f.P * LPB / FOLVE_W3_WG, f.cout * w.tiles, njobs), block(FOLVE_W3_WG);
 #ifdef FOLVE_WALK_NO_PIN
     constexpr bool kPin = false;
 #else
