@@ -741,6 +741,12 @@ def main():
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
     _, dt, _ = sharding.aggregate_throughput(S * T * P * args.steps, dt, dist, red_dev)   # max over ranks
+    # The hot path's one metric, max_output_value() (/root/reference/sound-processor.cc:116-125), of every stream of the job in
+    # global stream order: each rank's K3 keeps its streams' running maxima on the GPU; the ranks' shards are disjoint, so one
+    # sum-reduction of a 64 N-vector is the gather (the only inter-GPU traffic besides the barrier).
+    sync()
+    pk = [st.peaks() for st in streams]
+    peaks_abs = sharding.gather_stream_values(my_streams, [p_[1] for p_ in pk], S * world, dist, red_dev)
 
     # The same loop once more, long enough for the GPU's clocks to settle (a 20-step region is over in
     # 13 ms): reported beside `value`, never instead of it.
@@ -1086,6 +1092,8 @@ def main():
             "realtime_streams": int(mframes * 1e6 / FS),
             "steady_state": steady,
             "parity_rms": parity_abs, "parity_rel": parity_rel,
+            "stream_peaks": {"streams": int(len(peaks_abs)), "max_abs": round(float(peaks_abs.max()), 4), "min_abs": round(float(peaks_abs.min()), 4),
+                             "what": "max |output| of every stream of the job, gathered over the ranks (K3's per-stream maxima)"},
             "parity": "first two steps of streams %s vs the float64 linear convolution, gate %.0e" % (check, PARITY_TOL),
             "roofline": roofline,
             "roofline_streaming": streaming,

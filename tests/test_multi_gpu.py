@@ -99,6 +99,7 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["config"]["total_streams"] == 16 and out["value"] > 0
     assert out["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]
     assert out["process_group"] == {"backend": "gloo", "world_size": 2, "forced_at_world_size_1": False}
+    assert out["stream_peaks"]["streams"] == 16 and 0.5 < out["stream_peaks"]["min_abs"] <= out["stream_peaks"]["max_abs"] < 20   # gathered over both ranks
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel_ms"] > 0 and out["roofline"]["frac_lower_bound"] > 0
     cpu = out["cpu_baseline"]
     assert cpu and cpu["value"] > 0 and cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["sample"]
@@ -125,6 +126,7 @@ def test_bench_cfg5_shape_eight_ranks_512_streams_on_one_gpu():
     assert sorted(i for s in out["shards"] for i in s) == list(range(512)) and out["shards"][3][:3] == [3, 11, 19]
     assert out["process_group"] == {"backend": "gloo", "world_size": 8, "forced_at_world_size_1": False}
     assert out["parity_rms"] <= 1e-5 and out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    assert out["stream_peaks"]["streams"] == 512 and out["stream_peaks"]["min_abs"] > 0.5      # every stream's maximum arrived
 
 
 def test_bench_rccl_branch_runs_on_one_gpu():
@@ -141,6 +143,7 @@ def test_bench_rccl_branch_runs_on_one_gpu():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["process_group"] == {"backend": "nccl", "world_size": 1, "forced_at_world_size_1": True}
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_rms"] <= 1e-5
+    assert out["stream_peaks"]["streams"] == 8 and out["stream_peaks"]["min_abs"] > 0.5       # (the gather's reduction ran over RCCL)
 
 
 def test_harness_over_two_router_slots_with_numa_placement(tmp_path):
