@@ -189,11 +189,13 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
                 if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head);
                 if constexpr (un % 2 == 0) sp[un / 2].x = add_ab(w[un]);
                 else sp[un / 2].y = add_ab(w[un]);
-                // Four (I, R) accumulators and two for T, taken in turn — ir0 ir1 tt0 ir2 ir3 tt1 —: every packed FMA is six
-                // instructions away from the one it depends on.  That is what hipcc's hazard recognizer wants between two
-                // inline-asm statements that touch one register (it cannot see that they are plain VALU, and pads an s_nop
-                // wherever they are fewer than five apart); the statements are volatile so that the order stays this one (left
-                // free, the scheduler groups the accumulators, runs out of T products half way and pads the rest).
+                // Four (I, R) accumulators and two for T.  What decides the mix of compiler-generated and inline-asm arithmetic is
+                // hipcc's hazard recognizer: between two inline-asm statements that touch one register it counts no wait states
+                // (it cannot see what they are) and pads an s_nop before every re-use — eight per step when all fifty products were
+                // asm, whatever the number of accumulators.  So the (I, R) products, plain packed FMAs, are the compiler's
+                // (__builtin_elementwise_fma: it knows they need nothing), and only the T products, whose operand halves are
+                // crossed at odd steps, stay asm — two compiler FMAs between any two of them.  The asm statements are volatile so
+                // that they keep their order among themselves.
                 v2f ir[4], tt[2];
                 static_for<KRP>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
