@@ -38,7 +38,7 @@ std::atomic<int> g_run_ahead{-2};          // -2: not decided yet (environment);
 std::atomic<bool> g_device_peaks{true};
 std::atomic<int> g_survive{-1};            // -1: not decided yet (FOLVE_AMD_SURVIVE, default on)
 const int kMaxRunAhead = 1024;
-// 64 blocks = 12 s of 44.1 kHz audio per chunk: 8 MB of page-locked ring and 12.6 MB of delay line per open stereo file
+// 64 blocks = 12 s of 44.1 kHz audio per chunk: 16 MB of page-locked ring (8 MB without the input history: in place) and 12.6 MB of delay line per open stereo file
 // at 256 k taps.  Measured with 64 file threads on one MI355X: depth 8: 5.5, 32: 8.0, 64: 9.0, 128: 9.2 Gsamples/s.
 const int kDefaultRunAhead = 64;
 // What one processor may pin for its two chunks: streams of many channels run ahead by fewer blocks (a block of a
