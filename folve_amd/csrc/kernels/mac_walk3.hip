@@ -29,6 +29,10 @@
 // several paths per output, time tiles — is the walk of kernels.hip; tools/check_isa.py simulates these loops too.
 #include "walk_common.hpp"
 
+#ifndef FOLVE_W3_NIR
+#define FOLVE_W3_NIR 2            // (I, R) accumulators per lane: 2 (four measured: two packed adds per step more — cfg4 K2 +2 %, a 2 x 2 matrix +3.6 %)
+#endif
+
 namespace fk {
 namespace {
 
@@ -142,13 +146,14 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
         };
         const float2* xrow = X + (size_t)ring_slot(job.slot0, tb, ring) * P;
         const float2* const xend = X + (size_t)ring * P;
-        int left = __builtin_amdgcn_readfirstlane(nb);      // blocks not yet requested (a scalar, and the compiler is told so)
-        auto advance = [&]() {                              // past the tile's last block: stay on it (re-read from L2, never used:
-            const bool more_rows = left > 1;                // D rows of HBM traffic per wavefront and call otherwise — 57 MB of cfg3's 4.6 GB)
+        // Past the tile's last block the walk stays on it (re-read from L2, never used; running on into the ring's next rows
+        // would be D rows of HBM traffic per wavefront and call: 57 MB of cfg3's 4.6 GB) — by comparing row pointers, which
+        // needs no counter beside them.
+        const float2* const xlast = X + (size_t)ring_slot(job.slot0, tb + nb - 1, ring) * P;
+        auto advance = [&]() {
             const float2* nx = xrow + P;
             nx = (nx == xend) ? X : nx;
-            xrow = more_rows ? nx : xrow;
-            left = max(left - 1, 1);
+            xrow = (xrow == xlast) ? xrow : nx;
         };
         // the first even step's carry: the odd rows' products of T(0), all from the history
         v2f carry;
@@ -189,24 +194,25 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
                 if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head);
                 if constexpr (un % 2 == 0) sp[un / 2].x = add_ab(w[un]);
                 else sp[un / 2].y = add_ab(w[un]);
-                // Four (I, R) accumulators and two for T.  What decides the mix of compiler-generated and inline-asm arithmetic is
+                // Two (I, R) accumulators and two for T.  What decides the mix of compiler-generated and inline-asm arithmetic is
                 // hipcc's hazard recognizer: between two inline-asm statements that touch one register it counts no wait states
                 // (it cannot see what they are) and pads an s_nop before every re-use — eight per step when all fifty products were
                 // asm, whatever the number of accumulators.  So the (I, R) products, plain packed FMAs, are the compiler's
                 // (__builtin_elementwise_fma: it knows they need nothing), and only the T products, whose operand halves are
                 // crossed at odd steps, stay asm — two compiler FMAs between any two of them.  The asm statements are volatile so
                 // that they keep their order among themselves.
+                constexpr int NIR = FOLVE_W3_NIR;
                 v2f ir[4], tt[2];
                 static_for<KRP>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
                     constexpr int j0 = 2 * q, j1 = 2 * q + 1;
                     // (the (I, R) products are plain packed FMAs: left to the compiler, which knows that they need no wait states;
                     // between inline-asm statements its hazard recognizer counts none and pads)
-                    if constexpr (j0 < 4) ir[j0 % 4] = w[(u - j0 + 2 * W) % W] * ge[j0];
-                    else ir[j0 % 4] = __builtin_elementwise_fma(w[(u - j0 + 2 * W) % W], ge[j0], ir[j0 % 4]);
+                    if constexpr (j0 < NIR) ir[j0 % NIR] = w[(u - j0 + 2 * W) % W] * ge[j0];
+                    else ir[j0 % NIR] = __builtin_elementwise_fma(w[(u - j0 + 2 * W) % W], ge[j0], ir[j0 % NIR]);
                     if constexpr (j1 < KR) {
-                        if constexpr (j1 < 4) ir[j1 % 4] = w[(u - j1 + 2 * W) % W] * ge[j1];
-                        else ir[j1 % 4] = __builtin_elementwise_fma(w[(u - j1 + 2 * W) % W], ge[j1], ir[j1 % 4]);
+                        if constexpr (j1 < NIR) ir[j1 % NIR] = w[(u - j1 + 2 * W) % W] * ge[j1];
+                        else ir[j1 % NIR] = __builtin_elementwise_fma(w[(u - j1 + 2 * W) % W], ge[j1], ir[j1 % NIR]);
                     }
                     if constexpr (u % 2 == 0) {              // aligned pairs: low half for T(u), high half for T(u + 2)
                         constexpr int p = ((u - 2 * q + 2 * W) % W) / 2;
@@ -220,32 +226,45 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
                 });
                 // The reduction is ONE asm block: between separate statements hipcc's hazard recognizer pads an s_nop in front of
                 // every dependent packed add (eight per step), and the hardware interlocks plain VALU dependencies by itself.
-                //   ir[0] = ir[0] + ir[1] + ir[2] + ir[3] = (I, R);  tt[0] = tt[0] + tt[1];
+                //   ir[0] = ir[0] + ir[1] (+ ir[2] + ir[3]) = (I, R);  tt[0] = tt[0] + tt[1];
                 //   (T, T) = an even step: low half now + the high half carried from two steps ago; an odd one: low + high;
                 //   sum = (T, T) + (R, I) * sel.lo + (I, R) * sel.hi      sel = (1, 0), the packed lane's (0, 1): it takes (I, R)
                 //   as they are (its T is zero: it keeps zeros in place of c) — two packed FMAs where selects would need the
                 //   halves of a register pair, which an asm operand cannot name.
                 v2f sum;
-                static_assert(KR >= 4 && KRP >= 2, "four (I, R) accumulators and two for T are in use");
-#define FK_W3_HEAD                            \
+                static_assert(KR >= 4 && KRP >= 2, "up to four (I, R) accumulators and two for T are in use");
+#define FK_W3_HEAD4                           \
     "v_pk_add_f32 %1, %1, %4\n\t"             \
     "v_pk_add_f32 %3, %3, %8\n\t"             \
     "v_pk_add_f32 %2, %2, %5\n\t"             \
     "v_pk_add_f32 %1, %1, %3\n\t"
+#define FK_W3_HEAD2                           \
+    "v_pk_add_f32 %1, %1, %4\n\t"             \
+    "v_pk_add_f32 %2, %2, %5\n\t"
 #define FK_W3_TAIL                                                           \
     "v_pk_fma_f32 %0, %1, %7, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"       \
     "v_pk_fma_f32 %0, %1, %7, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+#define FK_W3_EVEN "v_pk_add_f32 %0, %2, %6 op_sel:[0,1] op_sel_hi:[0,1]\n\t"
+#define FK_W3_ODD "v_pk_add_f32 %0, %2, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+                if constexpr (NIR == 2) ir[2] = ir[3] = v2f{0.f, 0.f};       // (operands of the asm below, not used by its two-accumulator form)
                 if constexpr (u % 2 == 0) {
-                    asm(FK_W3_HEAD "v_pk_add_f32 %0, %2, %6 op_sel:[0,1] op_sel_hi:[0,1]\n\t" FK_W3_TAIL
-                        : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
-                        : "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel), "v"(ir[3]));
+                    if constexpr (NIR == 4)
+                        asm(FK_W3_HEAD4 FK_W3_EVEN FK_W3_TAIL : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
+                            : "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel), "v"(ir[3]));
+                    else
+                        asm(FK_W3_HEAD2 FK_W3_EVEN FK_W3_TAIL : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]) : "v"(ir[0]), "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel));
                     carry = tt[0];
                 } else {
-                    asm(FK_W3_HEAD "v_pk_add_f32 %0, %2, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t" FK_W3_TAIL
-                        : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
-                        : "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel), "v"(ir[3]));
+                    if constexpr (NIR == 4)
+                        asm(FK_W3_HEAD4 FK_W3_ODD FK_W3_TAIL : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
+                            : "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel), "v"(ir[3]));
+                    else
+                        asm(FK_W3_HEAD2 FK_W3_ODD FK_W3_TAIL : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]) : "v"(ir[0]), "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel));
                 }
-#undef FK_W3_HEAD
+#undef FK_W3_HEAD4
+#undef FK_W3_HEAD2
+#undef FK_W3_EVEN
+#undef FK_W3_ODD
 #undef FK_W3_TAIL
                 if constexpr (LPB >= 2) {                    // the group's partial sums: every lane ends up with the total
                     sum.x += dpp_quad<0xB1>(sum.x); sum.y += dpp_quad<0xB1>(sum.y);
