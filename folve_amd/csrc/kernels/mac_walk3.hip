@@ -29,6 +29,11 @@
 // several paths per output, time tiles — is the walk of kernels.hip; tools/check_isa.py simulates these loops too.
 #include "walk_common.hpp"
 
+#ifndef FOLVE_W3_D33
+#define FOLVE_W3_D33 7            // prefetch depth of the 33-row windows with ONE lane per path (odd: 33 + D must be even; the forms
+                                 // with a hand-down have no registers for more than 7).  Measured (-DFOLVE_W3_D33=9): cfg3's K2 and the 2 x 2 matrix
+                                 // unchanged — the waits at s_waitcnt are not the loads' latency
+#endif
 #ifndef FOLVE_W3_NIR
 #define FOLVE_W3_NIR 2            // (I, R) accumulators per lane: 2 (four measured: two packed adds per step more — cfg4 K2 +2 %, a 2 x 2 matrix +3.6 %)
 #endif
@@ -318,12 +323,12 @@ hipError_t launch_walk3(const StreamJob* jobs, int njobs, const FilterDev& f, fl
                         hipStream_t st) {
     const JobRef jr = make_job_ref(jobs, tn);
     if (!walk3_has(ws.kr, ws.lpb, ws.np)) return hipErrorInvalidValue;
-    if (ws.np == 2 && ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 2, 2>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.np == 2 && ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, FOLVE_W3_D33, 2, 2>(jr, njobs, f, Y, ws, tn, st);
     if (ws.np == 2) return ws.kr == 17 ? launch3<17, 15, 4, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 4, 2>(jr, njobs, f, Y, ws, tn, st);
     if (ws.np == 4) {
         if (ws.kr == 9) return launch3<9, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
         if (ws.kr == 17) return launch3<17, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
-        return launch3<33, 7, 4, 4>(jr, njobs, f, Y, ws, tn, st);
+        return launch3<33, FOLVE_W3_D33, 4, 4>(jr, njobs, f, Y, ws, tn, st);
     }
     if (ws.lpb == 1) {
         switch (ws.kr) {
@@ -333,7 +338,7 @@ hipError_t launch_walk3(const StreamJob* jobs, int njobs, const FilterDev& f, fl
             case 21: return launch3<21, 7, 1>(jr, njobs, f, Y, ws, tn, st);
             case 26: return launch3<26, 8, 1>(jr, njobs, f, Y, ws, tn, st);
             case 29: return launch3<29, 7, 1>(jr, njobs, f, Y, ws, tn, st);
-            default: return launch3<33, 7, 1>(jr, njobs, f, Y, ws, tn, st);
+            default: return launch3<33, FOLVE_W3_D33, 1>(jr, njobs, f, Y, ws, tn, st);
         }
     }
     if (ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 2>(jr, njobs, f, Y, ws, tn, st);
