@@ -87,7 +87,12 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
     if (tb >= job.nblocks) return;
     const int nb = min(tile_len, job.nblocks - tb);
     const int P = f.P, K = f.K, ring = job.ring;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroup ids go round the 8 XCDs (id % 8), each with its own L2: in plain grid order an XCD would get every eighth
+    // 2 KB piece of every row.  The bin tiles are dealt so that every XCD gets a CONTIGUOUS eighth of each row instead
+    // (cfg3's K2 -1.2 %, the step -0.4 %, four A/B pairs on one box).
+    const int ntile = gridDim.x;
+    const int tile = (ntile % 8 == 0) ? (int)(blockIdx.x % 8) * (ntile / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int tid = tile * blockDim.x + threadIdx.x;
     const int bin = tid / LPB, sub = tid % LPB;
     const int pi = sub / LPP;                               // which of the output's paths this lane works for
     const int jb = (sub % LPP) * KR;                        // this lane's first row of G
