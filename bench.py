@@ -930,7 +930,7 @@ def main():
                 hplan.run()
             dh = (time.perf_counter() - th) / nh
             end_to_end = {"msamples_per_s": round(S * T * P * C / dh / 1e6, 1), "ms_per_step": round(dh * 1e3, 3),
-                          "buffers": "page-locked host memory, H2D + kernels + D2H pipelined in 8 chunks",
+                          "buffers": "page-locked host memory, H2D + kernels + D2H pipelined in chunks of whole streams (>= 64 MB each, up to 32)",
                           "pcie_GBs_each_way": round(S * T * P * C * 4 / dh / 1e9, 1), "matches_resident_run": ok}
             for s_ in hs:
                 s_.close()

@@ -46,7 +46,7 @@ int fail(int code, const char* fmt, ...) {
             return fail(FE_ERR_DEVICE, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int kJobSlots = 8;
+constexpr int kJobSlots = 64;    // (rounds whose descriptors may be in flight at once: a pipeline of more chunks than slots blocks its caller)
 
 // Frees a temporary device allocation on every exit path.
 struct DevTmp {
@@ -58,7 +58,8 @@ struct DevTmp {
 
 struct TableOffsets { int o[4]; int total; };
 
-constexpr int kMaxChunks = 8;     // measured on cfg3: 2 chunks 4.9 ms, 4: 4.2, 8: 3.9, 16: 8.9 (launches too small)
+constexpr int kMaxChunks = 32;    // (how many a batch gets: run_pipelined.  Until round 5 this was 8 and "16: launches too small" — what made 16
+                                  // chunks slow was the eight descriptor slots: the ninth round in flight blocked its caller)
 constexpr int kLanes = 2;
 
 // A launch lane: a HIP stream with its own K2 scratch.  Synchronous and device-pointer calls run on lane 0
@@ -508,7 +509,11 @@ int run_pipelined(fe_engine* e, fe_stream* const* streams, int n, const float* c
     // chunk boundaries: whole streams, about equal frame counts
     long long total = 0;
     for (int i = 0; i < n; ++i) total += nframes[i] * (streams[i]->f->ninp + streams[i]->f->nout);
-    const int want = std::max(1, std::min(kMaxChunks, n / 2));
+    // Chunks of at least 64 MB of PCM (in + out), at most kMaxChunks and at most one per two streams: the pipeline's fill and
+    // drain cost one chunk's copy each, so a big batch wants many (cfg3's 256-block batch, 2.1 GB: 8 chunks 25.2 - 28.3 ms,
+    // 32 chunks 23.3 - 25.8), a small one few (its launches must not get too small).
+    const int by_bytes = (int)std::min<long long>(kMaxChunks, total * (long long)sizeof(float) / ((long long)64 << 20));
+    const int want = std::max(1, std::min(std::max(8, by_bytes), n / 2));
     int first[kMaxChunks + 1];
     int chunks = 0;
     long long acc = 0;
