@@ -127,7 +127,7 @@ def main():
             outs.append(p.write_processed(r))
             done += r
             blocks += 1
-            if blocks == KILL_AT and gate.wait() == 0:
+            if blocks == KILL_AT and gate.wait(timeout=300) == 0:      # (a thread that died would otherwise leave the others here for good)
                 assert L.fe_engine_set_tuning(engines[BAD], capi.FE_TUNE_FAIL_NEXT, -1) == 0
         outs_bad[i] = np.concatenate(outs, 0)
         # ... then its share of the other 448
