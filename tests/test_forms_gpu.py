@@ -504,6 +504,30 @@ def test_walk_window_for_a_short_filter_matrix(tuned, oracle):
     assert tuned.last_kernels()["mac"] == "mac_walk3_kernel<13, 7, true, 1, 1>", tuned.last_kernels()
 
 
+@pytest.mark.parametrize("size,window", [(65536, 9), (98304, 13), (131072, 17), (163840, 21), (204800, 26), (229376, 29), (262144, 33)])
+def test_walk_window_ladder_in_both_forms(tuned, oracle, size, window):
+    """One lane per bin has a ladder of windows (9 / 13 / 17 / 21 / 26 / 29 / 33 rows of G): every rung, in the four-FMA and
+    in the three-FMA form (whose prefetch depth differs at 26 rows: the ring must have an even number of slots), launches
+    the instantiation it should and agrees with the general kernel; odd tile lengths, a ragged last block."""
+    rng = np.random.default_rng(size)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    _, flt, _ = make_pair(tuned, oracle, 2, 2, size, paths)
+    P, K = flt.block_size, flt.partitions
+    assert K + 1 <= window
+    T, S = 2 * K + 5, 3
+    xs = [rng.uniform(-1, 1, (T * P - 501 * s - 1, 2)).astype(np.float32) for s in range(S)]
+    tuned.set_tuning(mac_form=1)
+    ref = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+    for fma, name in ((4, "mac_walk_kernel<%d, 7, true, 4, 1, 1>" % window),
+                      (3, "mac_walk3_kernel<%d, %d, true, 1, 1>" % (window, 8 if window == 26 else 7))):
+        for tiles in (1, 3):
+            tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=tiles, walk_fma=fma)
+            ys = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+            assert tuned.last_kernels()["mac"] == name, tuned.last_kernels()
+            for s in range(S):
+                assert _rms(ys[s] - ref[s]) <= 2e-6, (fma, tiles, s)
+
+
 def test_three_fma_walk_at_cfg3_and_cfg4_shapes_against_float64(tuned, oracle):
     """The three-FMA walk's rounding (its three sums have the magnitude |x||g|, the four-FMA form's |Re|, |Im|) where it
     counts: cfg3's filter (K = 32, one lane per bin: 33 rows) and cfg4's (K = 64, two lanes) over calls long enough for the
