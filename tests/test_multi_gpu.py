@@ -65,6 +65,21 @@ def test_cfg5_shape_eight_slots_512_streams_and_one_gpu_going_bad(tmp_path):
     assert out["state_back"] == 0 and out["back_on_bad"] == 8 and out["rms_back"] <= 1e-5
 
 
+def test_an_open_file_moves_at_every_depth_and_position(tmp_path):
+    """tests/survive_worker.py: one file, two router slots on device 0; the slot's engine dies after 0 / 2 / 40 / all whole
+    blocks have been handed out, at run-ahead depths 1 / 4 / 64, through a stereo K = 25 filter and a 2 -> 3 channel one.  Every
+    file equals its reference (float64 convolution / closed form), moved exactly once, no silent block, same peak."""
+    env = dict(os.environ, FOLVE_AMD_DEVICES="0,0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "survive_worker.py"), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("SURVIVE_JSON ")][-1][len("SURVIVE_JSON "):])
+    assert len(out["cases"]) == 24
+    for c in out["cases"]:
+        assert c["rms"] <= 1e-5 and c["silent_blocks"] == 0 and c["ok"] == 1 and c["peak_err"] <= 1e-6, c
+        assert c["moves"] == 1 and c["engine_changed"], c
+
+
 def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
