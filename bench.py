@@ -231,10 +231,19 @@ OTHER_CONFIGS = {
                       "K = 25, 22 populated; /root/reference/demo-filters/SantaLucia/filter-44100.conf:39-53)"),
     "cfg4": dict(S=1, C=8, size=524288, populated=None, rate=96000,
                  what="one 96 kHz 8-channel stream, 8 diagonal paths of 524 288 taps (K = 64)"),
+    # not a BASELINE.json configuration: the headline's batch through a FULL filter matrix (a true-stereo reverb: four
+    # /impulse/read paths, zita-config.cc:55-177) — twice K2's arithmetic on the same bytes, where K2 is arithmetic-bound
+    "matrix": dict(S=64, C=2, size=262144, populated=None, rate=44100, full=True, cpu_leg=False, no_longer=True,
+                   what="cfg3's batch (64 stereo streams, 262 144 taps, K = 32) through a full 2 x 2 filter matrix: four paths, "
+                        "every output the sum of two convolutions"),
 }
 
 
-def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=None, dev=0, check=True, frames=None, **_):
+def traffic_key(S, T, K, C, full=False):
+    return "S%d_T%d_K%d_C%d" % (S, T, K, C) + ("_full" if full else "")
+
+
+def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=None, dev=0, check=True, frames=None, full=False, **_):
     """One filter of C diagonal paths (`populated` taps at offset 500 plus a dirac at 0, or `size` dense taps), S streams,
     T-block calls.  Returns ms per call (wall clock over `steps` asynchronous calls), per-kernel ms (HIP events, a second
     loop), and — check=True — the rms deviation of the first call's output from the float64 convolution."""
@@ -248,7 +257,15 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
     flt = fa.Filter(eng, C, C, size)
     rng = np.random.default_rng(3)
     taps = []
-    for c in range(C):
+    cross = {}                                           # full matrix: taps of path (input, output)
+    if full:
+        for i in range(C):
+            for o in range(C):
+                h = rng.standard_normal(size).astype(np.float32)
+                h *= np.float32(0.5) / np.linalg.norm(h)
+                flt.add(i, o, h)
+                cross[(i, o)] = h
+    for c in range(0 if full else C):
         h = np.zeros(size, np.float32)
         if populated and populated < 4096:
             # a short FIR in a long impulse file (the lowpass demo): /impulse/read hands the engine the WHOLE file, zeros
@@ -285,7 +302,10 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
         n = min(T, 2 * K + 8) * P                        # long enough for every partition to act
         x0, y0 = xs[0][:n].cpu().numpy(), ys[0][:n].cpu().numpy()
         cc = [0, C - 1]
-        ref = conv_f64(x0[:, cc], [taps[c] for c in cc])
+        if full:
+            ref = sum(conv_f64(x0[:, [i] * len(cc)], [cross[(i, o)] for o in cc]) for i in range(C))
+        else:
+            ref = conv_f64(x0[:, cc], [taps[c] for c in cc])
         parity = max(rms(y0[:, cc] - ref), rms(y0[:, cc] - ref) / rms(ref))
         for st in streams:
             st.reset()
@@ -430,7 +450,7 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, lon
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            entry = json.load(open(tpath)).get("S%d_T%d_K%d_C%d" % (S, T, K, C)) or {}
+            entry = json.load(open(tpath)).get(traffic_key(S, T, K, C, cfg.get("full"))) or {}
         except Exception:
             entry = {}
     by = entry.get("bytes") or {}
@@ -463,7 +483,7 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, lon
     # whatever the call's length), so the run-ahead depth the caller chooses sets how much of the
     # roof a lone stream sees.  Reported beside the 256-block figure, never instead of it.
     longer = None
-    if longer_calls and not cfg.get("frames") and T < 1024:
+    if longer_calls and not cfg.get("frames") and not cfg.get("no_longer") and T < 1024:
         try:
             r4 = measure_config(T=1024, steps=max(20, steps // 3), tune=tune, dev=dev, check=False, **cfg)
             tb4 = tiled_bytes(P, K, 1024)
@@ -473,7 +493,7 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, lon
         except Exception as e:  # noqa: BLE001
             longer = {"error": repr(e)}
     cpu_leg = None
-    if cpu:
+    if cpu and cfg.get("cpu_leg", True):
         try:
             cpu_leg = cpu_for_config(cfg)
             one = cpu_leg["one_stream_one_core"]["value"]
@@ -482,7 +502,7 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, lon
             cpu_leg = {"error": repr(e)}
     why_none = None
     if not by:
-        why_none = note or "no PMC traffic profiled for this shape (profiles/traffic.json has no entry %s)" % ("S%d_T%d_K%d_C%d" % (S, T, K, C))
+        why_none = note or "no PMC traffic profiled for this shape (profiles/traffic.json has no entry %s)" % traffic_key(S, T, K, C, cfg.get("full"))
     return {"workload": "%s: %s; P=%d, %d blocks per call, PCM resident in HBM" % (name, cfg["what"], P, T),
             "msamples_per_s": round(r["msamples_per_s"], 1), "ms_per_call": round(r["ms_per_call"], 4),
             "realtime_factor": round(r["frames_per_call"] / (r["ms_per_call"] * 1e-3) / cfg["rate"], 0),
@@ -606,7 +626,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU baseline sample length (all-core leg)")
     ap.add_argument("--tune", default="", help="engine tuning for experiments, e.g. mac_form=16,fwd_run=8")
     ap.add_argument("--skip", default="", help="comma-separated extra legs to leave out: streaming,end_to_end,single_block,drop_in,configs,mixed")
-    ap.add_argument("--only-config", default="", choices=["", "cfg1", "cfg2", "cfg4"],
+    ap.add_argument("--only-config", default="", choices=["", "cfg1", "cfg2", "cfg4", "matrix"],
                     help="run only this configuration's loop and print its `configs` entry (what tools/profile.sh profiles)")
     ap.add_argument("--config-blocks", type=int, default=256, help="blocks per call of the cfg2 / cfg4 legs")
     args = ap.parse_args()

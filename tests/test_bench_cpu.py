@@ -134,3 +134,18 @@ def test_every_profiled_kernel_exists_in_the_built_library():
     missing = [(shape, role, name) for shape, e in tj.items() if isinstance(e, dict)
                for role, name in (e.get("kernels") or {}).items() if b.norm_kernel(name) not in built]
     assert not missing, missing
+
+
+def test_the_matrix_configuration_has_its_own_profile_entry():
+    """`bench.py --only-config matrix` (cfg3's batch through a full 2 x 2 filter matrix) shares S / T / K / C with the headline
+    shape: its traffic.json entry has a key of its own and was counted on the two-paths-per-output walk."""
+    import json
+    b = _bench()
+    assert b.traffic_key(64, 256, 32, 2) == "S64_T256_K32_C2" and b.traffic_key(64, 256, 32, 2, True) == "S64_T256_K32_C2_full"
+    cfg = b.OTHER_CONFIGS["matrix"]
+    assert cfg["full"] and (cfg["S"], cfg["C"], cfg["size"]) == (64, 2, 262144)
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    e, d = tj["S64_T256_K32_C2_full"], tj["S64_T256_K32_C2"]
+    assert b.norm_kernel(e["kernels"]["mac"]) == b.norm_kernel("mac_walk3_kernel<33, 7, true, 2, 2>")
+    assert b.norm_kernel(d["kernels"]["mac"]) == b.norm_kernel("mac_walk3_kernel<33, 7, true, 1, 1>")
+    assert 1.0 < e["bytes"]["mac"] / d["bytes"]["mac"] < 1.1            # the same rows, the second input's read beside the first

@@ -2,7 +2,8 @@
 bench.py reads: per shape, HBM bytes per launch of K1 / K2 / K3 (FETCH_SIZE x 2 + WRITE_SIZE, see the
 note written into the file) and the kernel-trace average durations of the same launches.
 
-usage: python tools/make_traffic.py <tag> <streams> <blocks> <K> <channels>
+usage: python tools/make_traffic.py <tag> <streams> <blocks> <K> <channels> [--run-ahead-only] [--full]
+(--full: the profiled filter was a full matrix — bench.py --only-config matrix; the key gets the suffix `_full`)
 The run-ahead launches (T blocks per call) and the one-block-per-call launches of the same bench run
 are told apart by kernel: walkers / mac_walk / mac_slide vs forward_kernel / mac_kernel<1> / inverse_kernel.
 """
@@ -60,6 +61,6 @@ for mode, blocks in ((("T", T), ("1", 1)) if "--run-ahead-only" not in sys.argv 
         if t:
             entry["avg_ns"][role] = round(t["avg_ns"], 1)
     if entry["bytes"]:
-        tj["S%d_T%d_K%d_C%d" % (S, blocks, K, C)] = entry
+        tj["S%d_T%d_K%d_C%d" % (S, blocks, K, C) + ("_full" if "--full" in sys.argv else "")] = entry
 json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps({k: v for k, v in tj.items() if k != "_comment"}, indent=1))
