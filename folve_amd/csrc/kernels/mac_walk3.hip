@@ -61,11 +61,32 @@ __device__ __forceinline__ void pk_fma_x(v2f& d, const v2f& a, const v2f& b) {
 // The hand-down of a lane set: every lane but the set's head takes the element that leaves its neighbour's window (one DPP
 // row shift per register), the head keeps what its load brought.  (A DPP bank mask cannot do the select: a bank is four
 // CONSECUTIVE lanes of a row, not lane % 4.)
-__device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool head) {
+// One v_cndmask_b32_dpp per register does both the shift and the select (D = VCC ? S1 : dpp(S0): the heads keep theirs;
+// a row's first lane has no source and is not written — it is a head): 2 VALU per step where a DPP move and a select each
+// took 4 (cfg4's K2 is 84 % VALU issue, SQ counters).  `heads`: the mask of the lane sets' first lanes, a scalar pair.
+#ifndef FOLVE_W3_PLAIN_DPP
+__device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool, unsigned long long heads) {
+    asm("s_mov_b64 vcc, %4\n\t"
+        "v_cndmask_b32_dpp %0, %2, %0, vcc row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %3, %1, vcc row_shr:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(mine.x), "+v"(mine.y) : "v"(leaving.x), "v"(leaving.y), "s"(heads) : "vcc");
+}
+// sum += its neighbour's (lane ^ 1 / lane ^ 2), every lane: the shift rides on the add's first operand.  (s_nop 1: a DPP
+// operand written by the VALU instruction in front needs two wait states, and inside an asm block nobody counts them.)
+template <int CTRL0, int CTRL1, int CTRL2, int CTRL3>
+__device__ __forceinline__ void add_across(v2f& sum) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:0xf"
+        : "+v"(sum.x), "+v"(sum.y) : "n"(CTRL0), "n"(CTRL1), "n"(CTRL2), "n"(CTRL3));
+}
+#else
+__device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool head, unsigned long long) {
     const float hx = dpp_row_shr1(leaving.x), hy = dpp_row_shr1(leaving.y);
     mine.x = head ? mine.x : hx;
     mine.y = head ? mine.y : hy;
 }
+#endif
 
 template <int KR, int D, bool PIN, int LPB = 1, int NP = 1>
 #ifndef FOLVE_W3_WG
@@ -97,6 +118,7 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
     const int pi = sub / LPP;                               // which of the output's paths this lane works for
     const int jb = (sub % LPP) * KR;                        // this lane's first row of G
     const bool head = sub % LPP == 0;                       // the lane of its set that takes the loaded element
+    const unsigned long long heads = LPP == 4 ? 0x1111111111111111ull : LPP == 2 ? 0x5555555555555555ull : ~0ull;
     const unsigned voff = (unsigned)bin * 8u;               // this thread's bin inside any spectrum row
     const bool packed = bin == 0;
     const int pe0 = f.out_first[o], pe1 = f.out_first[o + 1];
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
             advance();
         }
         if constexpr (PIN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(D - 1) : "memory");
-        if constexpr (LPP > 1) hand_down(w[0], w[D], head);
+        if constexpr (LPP > 1) hand_down(w[0], w[D], head, heads);
         sp[0].x = add_ab(w[0]);
         float2* __restrict__ yrow = Y + yrow0 * P;          // uniform: advances one row per step
         for (int t0 = 0; t0 < nb; t0 += W) {
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #endif
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[un]) : "n"(N) : "memory");
                 }
-                if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head);
+                if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head, heads);
                 if constexpr (un % 2 == 0) sp[un / 2].x = add_ab(w[un]);
                 else sp[un / 2].y = add_ab(w[un]);
                 // Two (I, R) accumulators and two for T.  What decides the mix of compiler-generated and inline-asm arithmetic is
@@ -276,12 +298,17 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #undef FK_W3_EVEN
 #undef FK_W3_ODD
 #undef FK_W3_TAIL
-                if constexpr (LPB >= 2) {                    // the group's partial sums: every lane ends up with the total
+#ifndef FOLVE_W3_PLAIN_DPP
+                if constexpr (LPB >= 2) add_across<1, 0, 3, 2>(sum);   // the group's partial sums: every lane ends up with the total
+                if constexpr (LPB >= 4) add_across<2, 3, 0, 1>(sum);
+#else
+                if constexpr (LPB >= 2) {
                     sum.x += dpp_quad<0xB1>(sum.x); sum.y += dpp_quad<0xB1>(sum.y);
                 }
                 if constexpr (LPB >= 4) {
                     sum.x += dpp_quad<0x4E>(sum.x); sum.y += dpp_quad<0x4E>(sum.y);
                 }
+#endif
 #ifdef FOLVE_W3_NOSTORE                                      // what-if build (tools/build_variant.sh): the walk without its stores
                 asm volatile("" : : "v"(sum));
 #else
