@@ -27,6 +27,13 @@
 //   with the four-FMA walk and with float64: tests/test_forms_gpu.py.
 // Everything else — window as prefetch ring, pinned loads with exact s_waitcnt, several lanes per bin with DPP hand-down,
 // several paths per output, time tiles — is the walk of kernels.hip; tools/check_isa.py simulates these loops too.
+//   What a step costs beside its arithmetic (round 5, measured in tools/micro/valu_rates.hip: every instruction a wavefront
+//   issues costs it ~3.4 cycles at two waves per SIMD, a scalar one as much as a vector one, a branch that is never taken
+//   ~16): the rows are BUFFER accesses with a 32-bit scalar row offset (one s_add where a 64-bit pointer took two, 32-bit
+//   compares for the ring's wrap and the tile's end), a store past the tile's end is out of the buffer's range and dropped
+//   by the hardware, so the walk asks once per group of up to 8 steps whether it is over, and the hand-down / the sum
+//   across a bin's lanes ride as DPP operands on the select / the add.  73.8 -> 66.0 instructions per step at 33 rows on
+//   one lane, 83.6 -> 73.2 on two.
 #include "walk_common.hpp"
 
 #ifndef FOLVE_W3_D33
@@ -143,18 +150,34 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
             constexpr int q = decltype(qc)::value;
             cp[q] = v2f{0.f, 0.f};
         });
+        // Every load of the prologue is issued before anything uses one (a scheduling barrier between the two halves): left to
+        // itself the scheduler has, in some instantiations, paired each load with its use — fifty round trips to memory one
+        // after the other in front of a lone stream's 32 steps (<26, 8>, <29, 7>: K2 20 -> 28 us).
         static_for<KR>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const bool on = path_on && jb + j < K;
-            const v2f v = ldrow_g(Hd + (size_t)(on ? jb + j : 0) * P);
-            const float c = on ? v.x : 0.f, d = on ? v.y : 0.f;
+            ge[j] = ldrow_g(Hd + (size_t)(on ? jb + j : 0) * P);
+        });
+        // history: block -j of the lane's frame (the window of lane `sub` starts KR * sub blocks back) in slot W - j, its s beside
+        // it; slot D (block -KR: the first element handed down to the next lane, a zero with one lane per bin) too
+        static_for<KR>([&](auto jc) {
+            constexpr int j = decltype(jc)::value + 1;      // 1 .. KR
+            constexpr int slot = W - j;
+            if constexpr (!(LPB == 1 && j == KR)) {
+                const bool on = path_on && jb + j < K;      // (an element no row will ever meet is a zero)
+                w[slot] = ldrow(X + (size_t)ring_slot(job.slot0, on ? tb - j - jb : tb, ring) * P);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KR>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const bool on = path_on && jb + j < K;
+            const float c = on ? ge[j].x : 0.f, d = on ? ge[j].y : 0.f;
             ge[j].x = packed ? c : d - c;
             ge[j].y = packed ? d : -(c + d);
             if constexpr (j % 2 == 0) cp[j / 2].x = packed ? 0.f : c;
             else cp[j / 2].y = packed ? 0.f : c;
         });
-        // history: block -j of the lane's frame (the window of lane `sub` starts KR * sub blocks back) in slot W - j, its s beside
-        // it; slot D (block -KR: the first element handed down to the next lane, a zero with one lane per bin) too
         static_for<W / 2>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
             sp[p] = v2f{0.f, 0.f};                           // (slots still in flight hold finite numbers: they are multiplied, by zeros)
@@ -165,27 +188,39 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
             if constexpr (LPB == 1 && j == KR) {
                 w[slot] = v2f{0.f, 0.f};
             } else {
-                const bool on = path_on && jb + j < K;      // (an element no row will ever meet is a zero)
-                const v2f v = ldrow(X + (size_t)ring_slot(job.slot0, on ? tb - j - jb : tb, ring) * P);
-                w[slot] = on ? v : v2f{0.f, 0.f};
+                const bool on = path_on && jb + j < K;
+                w[slot] = on ? w[slot] : v2f{0.f, 0.f};
                 if constexpr (slot % 2 == 0) sp[slot / 2].x = add_ab(w[slot]);
                 else sp[slot / 2].y = add_ab(w[slot]);
             }
         });
-        auto issue = [&](v2f& dst, const float2* rowbase) {
-            if constexpr (PIN) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff_x), "s"(rowbase) : "memory");
-            else dst = ldrow(rowbase);
+        // The walk's rows are addressed as BUFFER accesses: a fixed resource (the stream's ring / this tile's rows of Y) and a
+        // 32-bit scalar offset that moves one row per step — one s_add_u32 where a 64-bit row pointer took two instructions to
+        // move, and 32-bit compares for the ring's wrap and the tile's end.  A wavefront pays ~3.4 cycles for every instruction
+        // it issues, scalar ones included (tools/micro/valu_rates.hip): the pointer arithmetic was 12 of ~75 per step.
+        auto make_rsrc = [](const void* base, unsigned bytes) {   // raw buffer of `bytes` bytes: stride 0, gfx9's format word
+            // (the base is uniform, but where lanes also compute their own addresses from it the compiler keeps its copy in
+            // vector registers, and an asm operand gets no readfirstlane by itself)
+            const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
         };
-        const float2* xrow = X + (size_t)ring_slot(job.slot0, tb, ring) * P;
-        const float2* const xend = X + (size_t)ring * P;
+        const unsigned rb = (unsigned)P * 8u;                // a row, in bytes
+        const auto xres = make_rsrc(X, 0xffffffffu);
+        auto issue = [&](v2f& dst, unsigned row_off) {
+            if constexpr (PIN) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff_x), "s"(xres), "s"(row_off) : "memory");
+            else dst = *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)X + row_off + voff_x);
+        };
+        unsigned xo = (unsigned)ring_slot(job.slot0, tb, ring) * rb;       // the row the next load takes
+        const unsigned ring_bytes = (unsigned)ring * rb;
         // Past the tile's last block the walk stays on it (re-read from L2, never used; running on into the ring's next rows
-        // would be D rows of HBM traffic per wavefront and call: 57 MB of cfg3's 4.6 GB) — by comparing row pointers, which
-        // needs no counter beside them.
-        const float2* const xlast = X + (size_t)ring_slot(job.slot0, tb + nb - 1, ring) * P;
+        // would be D rows of HBM traffic per wavefront and call: 57 MB of cfg3's 4.6 GB).  Selects, not a branch: a branch that
+        // is never taken costs a wavefront ~16 cycles, a scalar instruction ~3.4 (tools/micro/valu_rates.hip).
+        const unsigned xlast = (unsigned)ring_slot(job.slot0, tb + nb - 1, ring) * rb;
         auto advance = [&]() {
-            const float2* nx = xrow + P;
-            nx = (nx == xend) ? X : nx;
-            xrow = (xrow == xlast) ? xrow : nx;
+            unsigned nx = xo + rb;
+            nx = (nx == ring_bytes) ? 0u : nx;
+            xo = (xo == xlast) ? xo : nx;
         };
         // the first even step's carry: the odd rows' products of T(0), all from the history
         v2f carry;
@@ -198,19 +233,34 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
         if constexpr (PIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G and the history have arrived: the count starts here
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            issue(w[d], xrow);
+            issue(w[d], xo);
             advance();
         }
         if constexpr (PIN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(D - 1) : "memory");
         if constexpr (LPP > 1) hand_down(w[0], w[D], head, heads);
         sp[0].x = add_ab(w[0]);
-        float2* __restrict__ yrow = Y + yrow0 * P;          // uniform: advances one row per step
-        for (int t0 = 0; t0 < nb; t0 += W) {
-            const bool more = static_all<W>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
+        // The tile's rows of Y are a buffer of exactly nb rows and the row offset rides in the store's VECTOR offset (one
+        // v_add per step): a store past the tile's end is out of range and the hardware drops it (gfx9 checks the vector
+        // offset against num_records, not the scalar one).  So the walk need not ask at every step whether it is over — a
+        // compare and a branch, ~20 cycles of a step's ~250 — but once per group of G steps; the up to G - 1 steps beyond the
+        // end compute on the (clamped) last rows and store nowhere.
+#ifdef FOLVE_W3_G
+        constexpr int G = FOLVE_W3_G;
+#else
+        constexpr int G = W % 8 == 0 ? 8 : W % 4 == 0 ? 4 : 2;
+#endif
+        float2* const ybase = Y + yrow0 * P;                // this tile's rows of Y: a row per step
+        const auto yres = make_rsrc(ybase, (unsigned)nb * rb);
+        unsigned voff_y = voff;
+        int left = nb;                                       // steps to go, counted per group
+        for (;;) {                                           // (nb >= 1)
+            asm volatile("s_setprio 0");                     // (does nothing: marks the loop's head for tools/check_isa.py, whatever the block layout)
+            const bool more = static_all<W / G>([&](auto gc) {
+              static_for<G>([&](auto ic) {
+                constexpr int u = decltype(gc)::value * G + decltype(ic)::value;
                 constexpr int un = (u + 1) % W;              // the next step's slot
 #ifndef FOLVE_W3_NOLOAD                                      // what-if build: ... without its in-loop loads
-                issue(w[(u + D) % W], xrow);
+                issue(w[(u + D) % W], xo);
 #endif
                 advance();
                 if constexpr (PIN) {
@@ -312,11 +362,13 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #ifdef FOLVE_W3_NOSTORE                                      // what-if build (tools/build_variant.sh): the walk without its stores
                 asm volatile("" : : "v"(sum));
 #else
-                if constexpr (PIN) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(sum), "s"(yrow) : "memory");
-                else *(FK_GLOBAL v2f*)((FK_GLOBAL char*)yrow + voff) = sum;
+                if constexpr (PIN) asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(sum), "v"(voff_y), "s"(yres) : "memory");
+                else if (voff_y < (unsigned)nb * rb) *(FK_GLOBAL v2f*)((FK_GLOBAL char*)ybase + voff_y) = sum;
 #endif
-                yrow += P;
-                return t0 + u + 1 < nb;
+                voff_y += rb;
+              });
+              left -= G;
+              return left > 0;
             });
             if (!more) break;
         }

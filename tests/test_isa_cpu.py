@@ -52,7 +52,7 @@ def test_the_checker_sees_what_it_is_there_for():
             return l.replace(m.group(0), "vmcnt(%d)" % (int(m.group(1)) + 1)) if (m and l in loop) else l
 
         assert check_isa.check_walk_loop(name, [weaken(l) for l in body])
-        idx = [i for i, l in enumerate(body) if l.startswith("global_load_dwordx2") and l in loop][2]
+        idx = [i for i, l in enumerate(body) if l.startswith(("global_load_dwordx2", "buffer_load_dwordx2")) and l in loop][2]
         dst = check_isa.vregs(check_isa.split_operands(body[idx])[1][0])[0]
         assert any("v_mov_b32" in p for p in check_isa.check_walk_loop(name, body[:idx + 1] + ["v_mov_b32_e32 v250, v%d" % dst] + body[idx + 1:]))
         assert any("expected (KR + D)" in p for p in check_isa.check_walk_loop(name, body[:idx + 1] + ["global_load_dwordx2 v[252:253], v0, s[0:1]"] + body[idx + 1:]))

@@ -131,8 +131,48 @@ def function_bodies(co, want):
 
 
 def loop_region(body):
-    """The instructions of the loop closed by the function's last backward s_branch, in order, or None."""
+    """The instructions of the walk loop in the order the walk executes them, or None.  mac_walk3.hip marks its loop's head
+    with an `s_setprio 0`: from there the hot path is followed — a forward conditional branch inside the loop is an exit and is not taken, an s_branch
+    and a conditional branch back to the head are — until it comes back to the marker.  Without a marker (kernels.hip): the loop closed by the function's last backward s_branch."""
     labels = {l.split()[1]: i for i, l in enumerate(body) if l.startswith("LABEL ")}
+    marks = [i for i, l in enumerate(body) if l.startswith("s_setprio")]
+    if len(marks) == 1:
+        def leads_to_head(i):
+            """Does straight-line code from i (following s_branch only) reach the marker?  (The compiler may rotate the loop:
+            the back edge then lands some steps in front of the marker.)"""
+            for _ in range(len(body)):
+                if i >= len(body):
+                    return False
+                if i == marks[0]:
+                    return True
+                mn_, ops_ = split_operands(body[i])
+                if mn_ == "s_endpgm":
+                    return False
+                # (s_cbranch_execnz: the structurizer's "always" — a walking wavefront's EXEC is never zero)
+                i = labels[ops_[0]] if (mn_ in ("s_branch", "s_cbranch_execnz") and ops_ and ops_[0] in labels) else i + 1
+            return False
+
+        out, pc = [], marks[0] + 1
+        while pc != marks[0] and len(out) <= len(body):
+            if pc >= len(body):
+                return None
+            l = body[pc]
+            mn, ops = split_operands(l)
+            if l.startswith("LABEL "):
+                pc += 1
+                continue
+            if mn == "s_endpgm":
+                return None
+            out.append(l)
+            if mn in ("s_branch", "s_cbranch_execnz") and ops and ops[0] in labels:
+                pc = labels[ops[0]]
+            elif mn == "s_cbranch_execz":
+                pc += 1
+            elif mn.startswith("s_cbranch") and ops and ops[0] in labels and leads_to_head(labels[ops[0]]):
+                pc = labels[ops[0]]                           # the back edge, where the compiler made it the conditional one
+            else:
+                pc += 1
+        return out if pc == marks[0] else None
     for i in range(len(body) - 1, -1, -1):
         mn, ops = split_operands(body[i])
         if mn == "s_branch" and ops and ops[0] in labels and labels[ops[0]] < i:
@@ -157,6 +197,10 @@ def check_walk_loop(name, body):
             mn, ops = split_operands(ins)
             if not mn:
                 continue
+            # (the three-FMA walk addresses its rows as buffer accesses — a fixed resource and a scalar row offset — so
+            # buffer_load_dwordx2 / buffer_store_dwordx2 ARE its loads and stores; any other buffer access is unexpected)
+            if mn in ("buffer_load_dwordx2", "buffer_store_dwordx2"):
+                mn = mn.replace("buffer_", "global_")
             if mn.startswith(("scratch_", "buffer_", "flat_")) or "accvgpr" in mn:
                 if rnd == 0:
                     problems.append("%s: `%s` inside the walk loop" % (name, ins.split("//")[0].strip()))

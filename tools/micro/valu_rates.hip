@@ -16,13 +16,15 @@ __device__ __forceinline__ void pk_plain(v2f& a, const v2f& x, const v2f& h) { a
 __device__ __forceinline__ void fma1(float& a, const float& x, const float& h) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(h)); }
 __device__ __forceinline__ void vadd(float& a, const float& x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(x)); }
 __device__ __forceinline__ void salu(int& s) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(s) : : "scc"); }
+// a compare and a conditional branch that is never taken (its target is the next instruction anyway)
+__device__ __forceinline__ void branch_nt(int& s) { asm volatile("s_cmp_eq_u32 %0, -1\n\ts_cbranch_scc1 1f\n1:" : "+s"(s) : : "scc"); }
 
 // MODE 0: 66 pk (today's walk: re + im per row)      1: 66 v_fma_f32        2: 33 pk(plain) + 33 v_fma_f32
 //      3: 33 pk(plain) + 17 pk(op_sel)  (three FMAs per MAC, T packed)      4: 132 v_fma_f32 (today's flops unpacked)
 //      5: 99 v_fma_f32 (three FMAs per MAC, nothing packed)                 6: 33 pk only
 // SAL: scalar instructions per iteration, spread evenly
 // VAL: other plain vector instructions per iteration (v_add_f32), spread evenly
-template <int MODE, int SAL, int VAL = 0>
+template <int MODE, int SAL, int VAL = 0, int BR = 0>
 __global__ __launch_bounds__(256) void k(float* out, const v2f* in, int iters, long long* cyc) {
     extern __shared__ float lds_pad[];      // only there to limit the workgroups per CU to exactly w
     v2f w[34], g[34], acc[4];
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void k(float* out, const v2f* in, int iters, l
             if constexpr (MODE == 6) { pk_plain(acc[j % 4], w[j], g[j]); }
             if constexpr (VAL > 0) { if constexpr ((j * VAL) / 33 != ((j + 1) * VAL) / 33) { sfor<((j + 1) * VAL) / 33 - (j * VAL) / 33>([&](auto ic) { vadd(t[decltype(ic)::value % 4], w[33].x); }); } }
             if constexpr (SAL > 0) { if constexpr ((j * SAL) / 33 != ((j + 1) * SAL) / 33) { sfor<((j + 1) * SAL) / 33 - (j * SAL) / 33>([&](auto) { salu(sc); }); } }
+            if constexpr (BR > 0) { if constexpr ((j * BR) / 33 != ((j + 1) * BR) / 33) { sfor<((j + 1) * BR) / 33 - (j * BR) / 33>([&](auto) { branch_nt(sc); }); } }
         });
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void k(float* out, const v2f* in, int iters, l
     if (threadIdx.x % 64 == 0) atomicAdd((unsigned long long*)cyc, (unsigned long long)(t1 - t0));
 }
 
-template <int MODE, int SAL, int VAL = 0>
+template <int MODE, int SAL, int VAL = 0, int BR = 0>
 void run(const char* what, int ninst) {
     v2f* in; float* out; long long* cyc;
     (void)hipMalloc(&in, 256 * 68 * sizeof(v2f)); (void)hipMemset(in, 0, 256 * 68 * sizeof(v2f));
@@ -60,15 +63,15 @@ void run(const char* what, int ninst) {
     (void)hipMalloc(&cyc, 8);
     const int iters = 4000;
     printf("%-58s", what); fflush(stdout);
-    (void)hipFuncSetAttribute((const void*)k<MODE, SAL, VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k<MODE, SAL, VAL, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int w = 1; w <= 3; ++w) {
         const int blocks = 256 * w;                 // 256-thread blocks, one wave per SIMD each: w waves per SIMD
         const size_t lds = (size_t)(150 * 1024 / w);   // ... and at most w of them fit a CU's 160 KB: every CU gets exactly w
-        k<MODE, SAL, VAL><<<blocks, 256, lds>>>(out, in, 10, cyc);
+        k<MODE, SAL, VAL, BR><<<blocks, 256, lds>>>(out, in, 10, cyc);
         (void)hipMemset(cyc, 0, 8);
         hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         (void)hipEventRecord(a);
-        k<MODE, SAL, VAL><<<blocks, 256, lds>>>(out, in, iters, cyc);
+        k<MODE, SAL, VAL, BR><<<blocks, 256, lds>>>(out, in, iters, cyc);
         (void)hipEventRecord(b); (void)hipEventSynchronize(b);
         float ms; (void)hipEventElapsedTime(&ms, a, b);
         long long c = 0; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
@@ -99,5 +102,11 @@ int main() {
     run<2, 15, 14>("3-FMA scalar T: 33 pk + 33 fma + 14 VALU + 15 SALU", 95);
     run<3, 8, 10>("3-FMA packed T, lean: 50 pk + 10 VALU + 8 SALU", 68);
     run<0, 8, 10>("4-FMA, lean: 66 pk + 10 VALU + 8 SALU", 84);
+    // what a never-taken branch costs beside scalar arithmetic (a compare + s_cbranch_scc1 each, counted as two instructions)
+    run<3, 8, 10, 1>("lean 3-FMA + 1 untaken branch (cmp + cbranch)", 70);
+    run<3, 8, 10, 2>("lean 3-FMA + 2 untaken branches", 72);
+    run<3, 8, 10, 4>("lean 3-FMA + 4 untaken branches", 76);
+    run<3, 10, 10>("lean 3-FMA + 2 SALU", 70);
+    run<3, 16, 10>("lean 3-FMA + 8 SALU", 76);
     return 0;
 }
