@@ -2199,7 +2199,9 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
     const bool paths_ok = shape.max_paths <= 1 ||
                           (shape.max_paths <= 4 && (unsigned long long)f.cin * (unsigned)tn.max_ring * f.P * 8ull < (1ull << 32) &&
                            (unsigned long long)shape.ndata * f.K * f.P * 8ull < (1ull << 32));
-    const bool walk_ok = paths_ok && choose_walk(f, njobs, max_blocks, np, &ws);
+    // (the three-FMA walk addresses a stream's ring and a tile's rows of Y by 32-bit byte offsets)
+    const bool offsets_ok = ((unsigned long long)tn.max_ring + 1) * f.P * 8ull < (1ull << 32) && ((unsigned long long)max_blocks + 8) * f.P * 8ull < (1ull << 32);
+    const bool walk_ok = paths_ok && offsets_ok && choose_walk(f, njobs, max_blocks, np, &ws);
     if (tn.walk_lpb > 0 && walk_ok) {                           // tests: pin the lanes per bin / the time tiles
         int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) && tn.walk_lpb >= np ? walk_rows_per_lane(f.K, tn.walk_lpb, np) : 0;
         if (kr) { ws.lpb = tn.walk_lpb; ws.kr = kr; }
