@@ -408,7 +408,7 @@ hipError_t launch_walk3(const StreamJob* jobs, int njobs, const FilterDev& f, fl
     const JobRef jr = make_job_ref(jobs, tn);
     if (!walk3_has(ws.kr, ws.lpb, ws.np)) return hipErrorInvalidValue;
     if (ws.np == 2 && ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, FOLVE_W3_D33, 2, 2>(jr, njobs, f, Y, ws, tn, st);
-    if (ws.np == 2) return ws.kr == 17 ? launch3<17, 15, 4, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 4, 2>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.np == 2) return ws.kr == 17 ? launch3<17, 15, 4, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, FOLVE_W3_D33, 4, 2>(jr, njobs, f, Y, ws, tn, st);
     if (ws.np == 4) {
         if (ws.kr == 9) return launch3<9, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
         if (ws.kr == 17) return launch3<17, 15, 4, 4>(jr, njobs, f, Y, ws, tn, st);
@@ -425,10 +425,10 @@ hipError_t launch_walk3(const StreamJob* jobs, int njobs, const FilterDev& f, fl
             default: return launch3<33, FOLVE_W3_D33, 1>(jr, njobs, f, Y, ws, tn, st);
         }
     }
-    if (ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, 7, 2>(jr, njobs, f, Y, ws, tn, st);
+    if (ws.lpb == 2) return ws.kr == 17 ? launch3<17, 15, 2>(jr, njobs, f, Y, ws, tn, st) : launch3<33, FOLVE_W3_D33, 2>(jr, njobs, f, Y, ws, tn, st);
     if (ws.kr == 9) return launch3<9, 15, 4>(jr, njobs, f, Y, ws, tn, st);
     if (ws.kr == 17) return launch3<17, 15, 4>(jr, njobs, f, Y, ws, tn, st);
-    return launch3<33, 7, 4>(jr, njobs, f, Y, ws, tn, st);
+    return launch3<33, FOLVE_W3_D33, 4>(jr, njobs, f, Y, ws, tn, st);
 }
 
 }  // namespace fk
