@@ -528,6 +528,30 @@ def test_walk_window_ladder_in_both_forms(tuned, oracle, size, window):
                 assert _rms(ys[s] - ref[s]) <= 2e-6, (fma, tiles, s)
 
 
+@pytest.mark.parametrize("size,block", [(256, 256), (300, 512), (700, 1024), (1500, 2048), (3000, 4096), (4097, 8192)])
+def test_the_walk_at_short_partitions(tuned, oracle, size, block):
+    """Filters of up to 4096 taps get partitions of 256 .. 4096 frames (zita-fconfig.cc:74-77): the walk's row is P * 8 bytes
+    then, its buffer offsets and the range-checked end of a tile scale with it.  Both walk forms, several tile counts, odd
+    call lengths and a ragged last block against the general kernels."""
+    rng = np.random.default_rng(size)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    paths[(0, 1)] = [(3, (rng.standard_normal(size - 3) * 0.05).astype(np.float32))]     # two paths into output 1: the lane sets
+    _, flt, _ = make_pair(tuned, oracle, 2, 2, size, paths)
+    P = flt.block_size
+    assert P == block
+    T, S = 45, 3
+    xs = [rng.uniform(-1, 1, (T * P - 7 * s - 1, 2)).astype(np.float32) for s in range(S)]
+    tuned.set_tuning(mac_form=1)
+    ref = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+    for fma in (4, 3):
+        for tiles in (1, 2, 5):
+            tuned.set_tuning(mac_form=100, walk_tiles=tiles, walk_fma=fma)
+            ys = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+            assert tuned.last_kernels()["mac"].startswith("mac_walk3_kernel<" if fma == 3 else "mac_walk_kernel<"), tuned.last_kernels()
+            for s in range(S):
+                assert _rms(ys[s] - ref[s]) <= 2e-6, (fma, tiles, s)
+
+
 def test_three_fma_walk_at_cfg3_and_cfg4_shapes_against_float64(tuned, oracle):
     """The three-FMA walk's rounding (its three sums have the magnitude |x||g|, the four-FMA form's |Re|, |Im|) where it
     counts: cfg3's filter (K = 32, one lane per bin: 33 rows) and cfg4's (K = 64, two lanes) over calls long enough for the
