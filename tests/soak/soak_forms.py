@@ -10,7 +10,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad, t0 = 0, time.time()
 for c in range(cases):
-    size = int(rng.choice([9000, 20000, 60000, 65536, 100000, 131072, 200000, 262144, 270000, 524288, 600000, 1048576]))
+    size = int(rng.choice([300, 700, 1500, 3000, 4096, 9000, 20000, 60000, 65536, 100000, 131072, 200000, 262144, 270000, 524288, 600000, 1048576]))
     ch = int(rng.choice([1, 2, 2, 4, 6, 8]))                 # (4, 6, 8: the channel-pair K1 / K3)
     S = int(rng.integers(1, 7))
     T = int(rng.integers(1, 90)) if size <= 270000 else int(rng.integers(1, 200))
