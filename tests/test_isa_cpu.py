@@ -1,7 +1,8 @@
 """CPU: static checks of the built gfx950 code object (tools/check_isa.py).
 
-K2's whole-call walk (`mac_walk_kernel<.., PIN = true, ..>`, folve_amd/csrc/kernels/kernels.hip) issues its window loads
-by inline asm and waits with hand-counted `s_waitcnt vmcnt(N)`; it is only correct while no window register is spilled or
+K2's whole-call walk (`mac_walk_kernel<.., PIN = true, ..>`, folve_amd/csrc/kernels/kernels.hip; the three-FMA form
+`mac_walk3_kernel`, kernels/mac_walk3.hip, with buffer-addressed rows) issues its window loads by inline asm and waits with
+hand-counted `s_waitcnt vmcnt(N)`; it is only correct while no window register is spilled or
 copied and the loop holds exactly the memory instructions the counts assume.  A parity run can pass with that broken (the
 stale read depends on timing), so the condition is checked on the ISA itself: resource notes of every instantiation and a
 simulation of every walk loop against the hardware's in-order memory counter.  hipcc cross-compiles in the build

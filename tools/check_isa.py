@@ -19,7 +19,11 @@ Checks
 
 The three-FMA walk (kernels/mac_walk3.hip, `mac_walk3_kernel<KR, D, PIN, LPB, NP>`, its own object file) has the same loop
 structure — one pinned load and one store per step, KR + D steps per round — and is checked the same way; its window of
-(a + b) sums is written by VALU instructions only, so nothing of it is ever in flight.
+(a + b) sums is written by VALU instructions only, so nothing of it is ever in flight.  Its rows are BUFFER accesses
+(`buffer_load_dwordx2` / `buffer_store_dwordx2` with a scalar row offset: these two count as the walk's loads and stores,
+any other buffer access is flagged), it leaves its loop once per group of steps, and the compiler may rotate the loop or
+make the back edge the conditional branch: the loop is found from an `s_setprio 0` marker at its head and followed along
+its hot path (`loop_region`).
 
 usage: check_isa.py [--json] [--object PATH]      exit code 0 = clean   (default: kernels.o and mac_walk3.o)
 """
