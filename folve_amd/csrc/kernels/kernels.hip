@@ -1113,8 +1113,17 @@ __global__ __launch_bounds__(WaveGeom<LOG2P>::NT, 4) void inverse_walker_kernel(
                             if constexpr (MC) {
                                 float* __restrict__ r = out + (size_t)(fb + 2 * c * NT) * cout;
                                 const unsigned toff = (unsigned)t * 4u * (unsigned)cout;
+#ifdef FOLVE_WHATIF_QUAD_STORES      // what-if (wrong output, same bytes, half the write requests): every other pair stores 16 bytes per frame for
+                                     // itself and its neighbour — what a four-channel workgroup would buy: cfg4 K3 67 -> 62.5 us, 1 x 8 ch x 1 024 blocks 226 -> 198
+                                     // (tools/build_variant.sh quadst -DFOLVE_WHATIF_QUAD_STORES; tools/mc_walker_probe.py)
+                                if ((o0 & 2) == 0) {
+                                    *(FK_GLOBAL v4f*)((FK_GLOBAL char*)r + toff) = v4f{l.x, z.x, l.x, z.x};
+                                    *(FK_GLOBAL v4f*)((FK_GLOBAL char*)(r + NT * cout) + toff) = v4f{l.y, z.y, l.y, z.y};
+                                }
+#else
                                 gst_u2(r, toff, float2{l.x, z.x});                      // frame fb + 2 c NT + t
                                 gst_u2(r + NT * cout, toff, float2{l.y, z.y});          // and the one NT frames on
+#endif
                             } else {
                                 gst_u4_once(out + (fb + 2 * c * NT) * 2, (unsigned)t * 16u, float4{l.x, z.x, l.y, z.y});   // frame fb + 2q - P
                             }
