@@ -239,6 +239,15 @@ OTHER_CONFIGS = {
 }
 
 
+def fit_trace_to_wall(trace_ms, event_ms, wall_ms):
+    """The factor (<= 1) by which a profile's kernel-trace times of a call's three kernels must shrink so that they do not
+    exceed the call's wall time of THIS run."""
+    if not trace_ms or len(trace_ms) != len(event_ms):       # (event times hold the launch boundaries: the two kinds do not add up)
+        return 1.0
+    tsum = sum(trace_ms.values())
+    return 1.0 if (tsum <= wall_ms or tsum <= 0) else wall_ms / tsum
+
+
 def traffic_key(S, T, K, C, full=False):
     return "S%d_T%d_K%d_C%d" % (S, T, K, C) + ("_full" if full else "")
 
@@ -467,12 +476,16 @@ def config_line(name, T, steps=100, tune=None, dev=0, check=True, cpu=False, lon
     # average (`trace_us`), printed beside the event time, and `frac` divides by that.
     trace = entry.get("avg_ns") or {}
     kernels = {}
+    # (a box faster than the one that took the profile: the profile's kernel times, which this run's call cannot exceed, are
+    # scaled down to the call's wall time — and say so)
+    fit = fit_trace_to_wall({k: trace[k] / 1e6 for k in kms if by.get(k) and trace.get(k) and kms[k] < 0.15}, kms, r["ms_per_call"])
     for k in kms:
         short = by.get(k) and trace.get(k) and kms[k] < 0.15
-        t_ms = trace[k] / 1e6 if short else kms[k]
+        t_ms = trace[k] / 1e6 * fit if short else kms[k]
         kernels[k] = {"ms": round(t_ms, 4), "event_ms": round(kms[k], 4),
                       "trace_us": round(trace[k] / 1e3, 2) if (by.get(k) and trace.get(k)) else None,
-                      "time_source": ("rocprofv3 kernel trace of profile %s (a launch this short: the event time includes the launch boundary)" % entry.get("profile"))
+                      "time_source": ("rocprofv3 kernel trace of profile %s (a launch this short: the event time includes the launch boundary)%s"
+                                      % (entry.get("profile"), "" if fit == 1.0 else "; x %.3f: this box's call is shorter than the profiled kernels' sum" % fit))
                       if short else "HIP events in this run",
                       "traffic": by.get(k),
                       "frac": round(by[k] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if by.get(k) else None,

@@ -149,3 +149,16 @@ def test_the_matrix_configuration_has_its_own_profile_entry():
     assert b.norm_kernel(e["kernels"]["mac"]) == b.norm_kernel("mac_walk3_kernel<33, 7, true, 2, 2>")
     assert b.norm_kernel(d["kernels"]["mac"]) == b.norm_kernel("mac_walk3_kernel<33, 7, true, 1, 1>")
     assert 1.0 < e["bytes"]["mac"] / d["bytes"]["mac"] < 1.1            # the same rows, the second input's read beside the first
+
+
+def test_trace_times_never_exceed_the_calls_wall_time():
+    """A launch of a few tens of microseconds is timed by the committed profile's kernel trace; on a box faster than the one
+    that took the profile those times are scaled to the call's wall time of this run (their sum cannot exceed it)."""
+    b = _bench()
+    ev = {"forward": 0.025, "mac": 0.020, "inverse": 0.026}
+    tr = {"forward": 0.0217, "mac": 0.0158, "inverse": 0.0216}
+    assert b.fit_trace_to_wall(tr, ev, 0.0617) == 1.0                       # 59.1 us of kernels in a 61.7 us call
+    f = b.fit_trace_to_wall(tr, ev, 0.0570)                                  # a faster box: 57.0 us per call
+    assert 0.96 < f < 0.97 and abs(sum(v * f for v in tr.values()) - 0.0570) < 1e-9
+    assert b.fit_trace_to_wall({"mac": 0.0158}, ev, 0.0617) == 1.0          # (only when all three are trace times)
+    assert b.fit_trace_to_wall({}, ev, 0.05) == 1.0
