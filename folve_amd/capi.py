@@ -90,6 +90,7 @@ ENGINE_SYMBOLS = [
     ("fe_debug_xlane", _i, [_vp, _vp]),
     ("fe_engine_set_profiling", _i, [_vp, _i]),
     ("fe_engine_get_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
+    ("fe_engine_get_kernel_profile", _i, [_vp, C.POINTER(_ll), C.POINTER(C.c_double)]),
     ("fe_engine_reset_profile", _i, [_vp]),
     ("fe_engine_last_kernels", _i, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("fe_engine_hbm_rates", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
@@ -178,6 +179,13 @@ class Engine:
         n = (C.c_longlong * FE_K_COUNT)()
         ms = (C.c_double * FE_K_COUNT)()
         _chk(lib().fe_engine_get_profile(self.h, n, ms), "fe_engine_get_profile")
+        return {KERNEL_NAMES[k]: {"launches": int(n[k]), "ms": float(ms[k])} for k in range(FE_K_COUNT)}
+
+    def get_kernel_profile(self):
+        """Profiling mode 2 (set_profiling(2)): per role the dispatches timed and the sum of their own begin-to-end times."""
+        n = (C.c_longlong * FE_K_COUNT)()
+        ms = (C.c_double * FE_K_COUNT)()
+        _chk(lib().fe_engine_get_kernel_profile(self.h, n, ms), "fe_engine_get_kernel_profile")
         return {KERNEL_NAMES[k]: {"launches": int(n[k]), "ms": float(ms[k])} for k in range(FE_K_COUNT)}
 
     def last_kernels(self):

@@ -138,10 +138,18 @@ struct fe_engine {
     int fail_round_in = 0;               // test hook: the n-th launch round from now fails with FE_ERR_DEVICE (0: none, < 0: every round)
     int sync_in_flight = 0;              // synchronous zero-copy calls waiting (lock released) on lane 0
     bool tuning_single_lane = false;     // FE_TUNE_LANES = 1: every submitted batch on lane 0 (measurements)
-    bool profiling = false;
+    int profiling = 0;                   // fe_engine_set_profiling: 0 off, 1 events recorded between the launches, 2 events bound to the dispatches
     hipEvent_t pev[4] = {};
+    // mode 2: start / stop of each role's dispatch (hipExtLaunchKernelGGL), a ring of sets read back when a set comes round
+    // again or when the profile is asked for — the profiled rounds run back to back like the timed ones
+    static constexpr int kKevSets = 32;
+    hipEvent_t kev[kKevSets][FE_K_COUNT][2] = {};
+    bool kev_pending[kKevSets] = {};
+    int kev_next = 0;
     long long prof_launches[FE_K_COUNT] = {};
     double prof_ms[FE_K_COUNT] = {};
+    long long prof_kernel_launches[FE_K_COUNT] = {};
+    double prof_kernel_ms[FE_K_COUNT] = {};
     fk::LaunchNames last_names = {};     // the kernels of the most recent launch round (fe_engine_last_kernels)
 };
 
@@ -253,6 +261,21 @@ struct Item {
     unsigned int* blk_peaks = nullptr;   // device: this stream's per-block maxima of the call (advances with the rounds)
 };
 
+// Profiling mode 2: read one set of dispatch-bound events back — each dispatch's own begin-to-end (the command
+// processor's stamps of the packet: no launch boundary inside) — waiting for its round if it is still running.
+int harvest_kernel_events(fe_engine* e, int set) {
+    if (!e->kev_pending[set]) return FE_OK;
+    e->kev_pending[set] = false;
+    HIP_TRY(hipEventSynchronize(e->kev[set][FE_K_COUNT - 1][1]));
+    for (int k = 0; k < FE_K_COUNT; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->kev[set][k][0], e->kev[set][k][1]));
+        e->prof_kernel_ms[k] += ms;
+        e->prof_kernel_launches[k] += 1;
+    }
+    return FE_OK;
+}
+
 // One launch round over streams that share a filter.  Host-side stream state (ring position, block
 // count) advances only after all three launches were accepted: a failed round leaves every stream
 // where it was.
@@ -334,7 +357,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
         HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
     }
 
-    const bool prof = e->profiling;
+    const bool prof = e->profiling == 1, kprof = e->profiling == 2;
     if (e->fail_round_in < 0 || (e->fail_round_in > 0 && --e->fail_round_in == 0)) {   // test hook (fe_engine_set_tuning FE_TUNE_FAIL_NEXT): an injected device failure
         return fail(FE_ERR_DEVICE, "injected device failure (test hook)");
     }
@@ -345,6 +368,14 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
     tn.one_job = nj == 1 ? e->jobs_host[slot] : nullptr;
     tn.names = &e->last_names;
+    int kset = -1;
+    if (kprof) {
+        kset = e->kev_next;
+        e->kev_next = (e->kev_next + 1) % fe_engine::kKevSets;
+        int hrc = harvest_kernel_events(e, kset);
+        if (hrc) return hrc;
+        tn.kev = e->kev[kset];
+    }
     // (roctx, when a profiler listens: the three launches of this round under one named range)
     ftrace::Range round_range("folve round: filter %p (%d->%d ch, K=%d, P=%d) streams=%d blocks<=%d lane=%d", static_cast<void*>(f), f->ninp,
                               f->nout, f->K, f->P, nj, max_blocks, lane);
@@ -372,6 +403,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
             e->prof_launches[k] += 1;
         }
     }
+    if (kprof) e->kev_pending[kset] = true;
     // everything is enqueued: advance the streams (all later work is stream-ordered behind it)
     for (size_t i = 0; i < jobs.size(); ++i) {
         Item& it = *owners[i];
@@ -1151,6 +1183,9 @@ static void engine_release(fe_engine* e) {
         if (e->jobs_ev[i]) (void)hipEventDestroy(e->jobs_ev[i]);
     }
     for (int i = 0; i < 4; ++i) if (e->pev[i]) (void)hipEventDestroy(e->pev[i]);
+    for (auto& set : e->kev)
+        for (auto& role : set)
+            for (hipEvent_t ev : role) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ticket_events) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1795,7 +1830,15 @@ int fe_engine_probe(fe_engine* e) {
 int fe_engine_set_profiling(fe_engine* e, int on) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
-    e->profiling = on != 0;
+    if (on == 2 && !e->kev[0][0][0]) {             // the event ring of mode 2, on first use
+        HIP_TRY(hipSetDevice(e->device));
+        for (auto& set : e->kev)
+            for (auto& role : set)
+                for (hipEvent_t& ev : role) HIP_TRY(hipEventCreate(&ev));
+    }
+    if (e->profiling == 2 && on != 2)
+        for (int i = 0; i < fe_engine::kKevSets; ++i) { int rc = harvest_kernel_events(e, i); if (rc) return rc; }
+    e->profiling = on == 2 ? 2 : on != 0;
     return FE_OK;
 }
 
@@ -1814,6 +1857,17 @@ int fe_engine_get_profile(fe_engine* e, long long launches[FE_K_COUNT], double m
     for (int k = 0; k < FE_K_COUNT; ++k) {
         if (launches) launches[k] = e->prof_launches[k];
         if (ms) ms[k] = e->prof_ms[k];
+    }
+    return FE_OK;
+}
+
+int fe_engine_get_kernel_profile(fe_engine* e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]) {
+    if (!e) return fail(FE_ERR_PARAM, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (int i = 0; i < fe_engine::kKevSets; ++i) { int rc = harvest_kernel_events(e, i); if (rc) return rc; }
+    for (int k = 0; k < FE_K_COUNT; ++k) {
+        if (launches) launches[k] = e->prof_kernel_launches[k];
+        if (ms) ms[k] = e->prof_kernel_ms[k];
     }
     return FE_OK;
 }
@@ -1854,7 +1908,11 @@ static int hbm_rates_n(fe_engine* e, size_t bytes, int reps, double* gbs, int mo
 int fe_engine_reset_profile(fe_engine* e) {
     if (!e) return fail(FE_ERR_PARAM, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
-    for (int k = 0; k < FE_K_COUNT; ++k) { e->prof_launches[k] = 0; e->prof_ms[k] = 0.0; }
+    for (int i = 0; i < fe_engine::kKevSets; ++i) { int rc = harvest_kernel_events(e, i); if (rc) return rc; }
+    for (int k = 0; k < FE_K_COUNT; ++k) {
+        e->prof_launches[k] = 0; e->prof_ms[k] = 0.0;
+        e->prof_kernel_launches[k] = 0; e->prof_kernel_ms[k] = 0.0;
+    }
     return FE_OK;
 }
 

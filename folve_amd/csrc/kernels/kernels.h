@@ -64,6 +64,7 @@ struct Tuning {
     int walk_tiles = 0;     // K2 whole-call walk: time tiles per call
     int walk_fma = 0;       // K2 whole-call walk: 3 = the three-FMA form (mac_walk3.hip), 4 = the four-FMA form, 0 = by shape
     LaunchNames* names = nullptr;   // set per call: where the launchers note the kernels they chose
+    hipEvent_t (*kev)[2] = nullptr; // set per call while profiling: per role (0 = K1, 1 = K2, 2 = K3) a start / stop event to bind to the dispatch
     // set per call: the only descriptor of a one-stream launch, readable by the HOST.  Every kernel then receives it
     // by value among its arguments instead of fetching jobs[0] — a dependent read over the bus when the descriptors
     // sit in page-locked memory (2 us at the start of each of the three latency kernels), an upload in front of K1

@@ -2210,7 +2210,8 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
                            (unsigned long long)shape.ndata * f.K * f.P * 8ull < (1ull << 32));
     // (the three-FMA walk addresses a stream's ring and a tile's rows of Y by 32-bit byte offsets)
     const bool offsets_ok = ((unsigned long long)tn.max_ring + 1) * f.P * 8ull < (1ull << 32) && ((unsigned long long)max_blocks + 8) * f.P * 8ull < (1ull << 32);
-    const bool walk_ok = paths_ok && offsets_ok && choose_walk(f, njobs, max_blocks, np, &ws);
+    // (a limit of the three-FMA form alone: the four-FMA walk addresses by 64-bit pointers)
+    const bool walk_ok = paths_ok && choose_walk(f, njobs, max_blocks, np, &ws);
     if (tn.walk_lpb > 0 && walk_ok) {                           // tests: pin the lanes per bin / the time tiles
         int kr = (tn.walk_lpb == 1 || tn.walk_lpb == 2 || tn.walk_lpb == 4) && tn.walk_lpb >= np ? walk_rows_per_lane(f.K, tn.walk_lpb, np) : 0;
         if (kr) { ws.lpb = tn.walk_lpb; ws.kr = kr; }
@@ -2232,7 +2233,7 @@ hipError_t launch_mac(const StreamJob* jobs, int njobs, int max_blocks, const Fi
         // and fewer joules where it is memory (cfg3's batch at the power cap: the whole call 2.25 -> 2.19 ms, K1 and K3
         // included).  tn.walk_fma pins either form.
         const bool fma3 = tn.walk_fma == 3 || tn.walk_fma == 0;
-        if (fma3 && walk3_has(ws.kr, ws.lpb, ws.np)) return launch_walk3(jobs, njobs, f, Y, ws, tn, st);
+        if (fma3 && offsets_ok && walk3_has(ws.kr, ws.lpb, ws.np)) return launch_walk3(jobs, njobs, f, Y, ws, tn, st);
         // 256-thread workgroups: one wavefront per workgroup ran 11 % slower, two 3 % (a workgroup's four
         // waves start together and read 2 KB of a row between them: DRAM locality)
         if (ws.np == 2 && ws.lpb == 2) {

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <cxxabi.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,10 +107,14 @@ inline void note_kernel(const Tuning& tn, int role) {
     }();
     snprintf(tn.names->k[role], sizeof tn.names->k[role], "%s", name.c_str());
 }
-#define FK_LAUNCH(role, kern, grid, block, st, ...)                \
-    do {                                                           \
-        note_kernel<kern>(tn, role);                               \
-        hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__); \
+// (Tuning::kev, profiling: the launch carries a start and a stop event BOUND TO THE DISPATCH — hipExtLaunchKernelGGL —,
+// whose elapsed time is the command processor's begin-to-end of this one packet: what rocprofv3's kernel trace prints,
+// without the launch boundary an event recorded behind the kernel includes; tools/micro/ext_launch_timing.hip)
+#define FK_LAUNCH(role, kern, grid, block, st, ...)                                                                  \
+    do {                                                                                                             \
+        note_kernel<kern>(tn, role);                                                                                 \
+        if (tn.kev) hipExtLaunchKernelGGL(kern, grid, block, 0, st, tn.kev[role][0], tn.kev[role][1], 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                                              \
     } while (0)
 
 }  // namespace

@@ -208,11 +208,19 @@ int fe_engine_set_tuning(fe_engine *e, int knob, int value);
 /* Device self-test of the cross-lane exchange the FFT rows use (kernels.h launch_xlane_selftest). */
 int fe_debug_xlane(fe_engine *e, float *out512);
 
-/* ---- measurement hooks (bench.py: per-kernel HIP-event timing) ------------ */
+/* ---- measurement hooks (bench.py: per-kernel timing) ----------------------- */
 enum { FE_K_FORWARD = 0, FE_K_MAC = 1, FE_K_INVERSE = 2, FE_K_COUNT = 3 };
+/* on = 1: HIP events recorded between the three launches of every round, the round waited for (an event-to-event time
+ *         holds the kernel AND the launch boundary behind it: 4 - 7 us on MI355X);
+ * on = 2: a start and a stop event bound to each DISPATCH (hipExtLaunchKernelGGL): the command processor's begin-to-end
+ *         of that packet alone, the figure rocprofv3's kernel trace prints; rounds keep running back to back (a ring of
+ *         32 event sets, read back when a set comes round again or when the profile is asked for);
+ * on = 0: off.  Streams on this engine keep their results either way. */
 int fe_engine_set_profiling(fe_engine *e, int on);
-/* accumulated since the last reset: launches and milliseconds per kernel */
+/* accumulated since the last reset: launches and milliseconds per kernel (mode 1: event to event) */
 int fe_engine_get_profile(fe_engine *e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]);
+/* ... and of mode 2: each role's dispatches and the sum of their own durations */
+int fe_engine_get_kernel_profile(fe_engine *e, long long launches[FE_K_COUNT], double ms[FE_K_COUNT]);
 int fe_engine_reset_profile(fe_engine *e);
 /* The kernels of the engine's most recent launch round, one string per role (FE_K_FORWARD / FE_K_MAC / FE_K_INVERSE): the
  * template instantiation as rocprofv3 prints it without namespaces and arguments, e.g. "mac_walk_kernel<33, 7, true, 4, 1, 1>".

@@ -2,9 +2,12 @@
 the CPU count its baseline leg runs on, the power / clock reader.  No GPU, nothing under oracle/."""
 import importlib.util
 import os
+import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _bench():
@@ -27,6 +30,88 @@ def test_algorithmic_bytes_are_the_survey_figures():
     tb = b.tiled_bytes(8192, 32, 256)
     assert tb["mac"] == 8 * 8192 * (256 + 32) / 256 + 8 * 8192 and tb["mac"] < ab["mac"] / 8
     assert tb["total"] == tb["forward"] + tb["mac"] + tb["inverse"]
+
+
+def _canned_full_result(n_gpus=8):
+    """A full result dict of the size a real run produces: round 5's 23.9 KB line (profiles/r05_bench_20steps.json, the
+    one the driver could not parse) plus this round's keys and an 8-rank job's shards."""
+    import json
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_20steps.json")).read().strip().splitlines()[-1])
+    full["n_gpus"] = n_gpus
+    full["shards"] = [[r + n_gpus * i for i in range(64)] for r in range(n_gpus)]
+    full["process_group"] = {"backend": "nccl", "world_size": n_gpus, "forced_at_world_size_1": False}
+    full["roofline"]["k2_valu"] = {"tflops": 60.12, "peak": 157.3, "frac": 0.3822, "flops_per_launch": 53150220288, "sclk_mhz": 1730.0, "frac_at_sclk": 0.5302}
+    full["roofline"]["traffic_note"] = "x" * 900                       # prose of any length stays out of the line
+    for c in full["configs"].values():
+        c["roofline"]["k2_valu"] = {"tflops": 66.6, "peak": 157.3, "frac": 0.4234, "frac_at_sclk": 0.51, "sclk_mhz": 1990.0}
+        c["roofline"]["bound"] = "valu"
+    return full
+
+
+def test_contract_line_is_small():
+    """The driver keeps an 8 KB tail of stdout and parses the LAST line: round 5's 23.9 KB line came back `parsed: null`.
+    The line built from a full-size result must stay under 4 KB, round-trip through json, and carry the contract's keys,
+    `roofline` and `cpu_baseline` with the fields the contract names; everything else is in the details file it names."""
+    import json
+    from benchlib import line as L
+    full = _canned_full_result()
+    assert len(json.dumps(full)) > 20000                               # the input really is round 5's size
+    text = L.render(full)
+    assert len(text) < 4096 and "\n" not in text, len(text)
+    out = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "details"):
+        assert k in out, k
+    assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"] and out["unit"] == "Msamples/s"
+    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["partitions"] == 32
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_name", "kernel_ms", "kernels_ms",
+              "min_bytes_per_launch", "frac_lower_bound", "path", "k2_valu"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "valu") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = out["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "one_core", "zita_convolver_on_this_box"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert set(out["configs"]) == {"cfg1", "cfg2", "cfg4", "matrix"}
+    for c in out["configs"].values():
+        assert set(c) == {"msamples_per_s", "ms_per_call", "path_frac", "parity_rms", "bound", "k2_valu_frac"}
+    assert out["shards"]["streams_per_rank"] == [64] * 8 and out["process_group"]["world_size"] == 8
+    assert out["details"] == "bench_details.json"
+    # a failed leg and a missing CPU leg still give a parseable, small line
+    full["configs"]["cfg4"] = {"error": "RuntimeError('" + "y" * 500 + "')"}
+    full["cpu_baseline"] = None
+    out2 = json.loads(L.render(full))
+    assert len(L.render(full)) < 4096 and out2["cpu_baseline"] is None and "error" in out2["configs"]["cfg4"]
+
+
+def test_emit_prints_one_line_and_writes_the_details(tmp_path, capsys):
+    import json
+    from benchlib import line as L
+    full = _canned_full_result(2)
+    path = str(tmp_path / "details.json")
+    L.emit(full, path)
+    cap = capsys.readouterr()
+    lines = cap.out.splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096                    # ONE line on stdout
+    assert json.loads(lines[0])["details"] == path
+    det = json.load(open(path))
+    assert det["shards"] == full["shards"] and det["drop_in_threads"] == full["drop_in_threads"]     # nothing is lost
+    assert det["roofline"]["all_kernels"] == full["roofline"]["all_kernels"]
+
+
+def test_k2_flops_and_the_roof_that_binds():
+    """K2's issued flops: 6 per complex multiply-add in the three-FMA walk, 8 otherwise; cfg4 6.54 Gflop,
+    the 2 x 2 matrix 106 Gflop; `bound` is the larger fraction."""
+    from benchlib import formulas as F
+    from benchlib.configs import choose_bound
+    assert F.walk_flops("mac_walk3_kernel<33, 7, true, 2, 1>", 8192, 64, 256, 8) == 6 * 65 * 8192 * 256 * 8
+    assert round(F.walk_flops("mac_walk3_kernel<33, 7, true, 2, 2>", 8192, 32, 256, 128, 2) / 1e9) == 106
+    assert F.walk_flops("mac_walk_kernel<33, 7, true, 4, 1, 1>", 8192, 32, 256, 128) == 8 * 33 * 8192 * 256 * 128
+    v = F.valu_fractions(6.543e9, 0.0983, 1990.0)
+    assert abs(v["tflops"] - 66.56) < 0.1 and abs(v["frac"] - 0.423) < 2e-3 and abs(v["frac_at_sclk"] - 0.5104) < 2e-3
+    assert choose_bound(0.43, v) == "hbm" and choose_bound(0.40, v) == "valu" and choose_bound(None, v) == "valu"
+    assert choose_bound(0.66, None) == "hbm"
 
 
 def test_usable_cpus_is_bounded_by_the_affinity_mask():
@@ -151,14 +236,17 @@ def test_the_matrix_configuration_has_its_own_profile_entry():
     assert 1.0 < e["bytes"]["mac"] / d["bytes"]["mac"] < 1.1            # the same rows, the second input's read beside the first
 
 
-def test_trace_times_never_exceed_the_calls_wall_time():
-    """A launch of a few tens of microseconds is timed by the committed profile's kernel trace; on a box faster than the one
-    that took the profile those times are scaled to the call's wall time of this run (their sum cannot exceed it)."""
-    b = _bench()
-    ev = {"forward": 0.025, "mac": 0.020, "inverse": 0.026}
-    tr = {"forward": 0.0217, "mac": 0.0158, "inverse": 0.0216}
-    assert b.fit_trace_to_wall(tr, ev, 0.0617) == 1.0                       # 59.1 us of kernels in a 61.7 us call
-    f = b.fit_trace_to_wall(tr, ev, 0.0570)                                  # a faster box: 57.0 us per call
-    assert 0.96 < f < 0.97 and abs(sum(v * f for v in tr.values()) - 0.0570) < 1e-9
-    assert b.fit_trace_to_wall({"mac": 0.0158}, ev, 0.0617) == 1.0          # (only when all three are trace times)
-    assert b.fit_trace_to_wall({}, ev, 0.05) == 1.0
+def test_kernel_times_in_the_tables_are_this_runs():
+    """a per-kernel `ms` / `frac` must be of THIS run — the dispatch-bound event time — with the committed
+    profile's kernel-trace average beside it under its own key, never substituted or scaled to fit."""
+    from benchlib.configs import kernel_table
+    from benchlib.formulas import tiled_bytes
+    kms = {"forward": 0.0540, "mac": 0.1100, "inverse": 0.0630}             # K2 regressed from the profile's 98.3 us to 110
+    ev = {"forward": 0.0590, "mac": 0.1150, "inverse": 0.0690}
+    entry = {"profile": "r05_cfg4", "avg_ns": {"forward": 52600, "mac": 98300, "inverse": 62100},
+             "kernels": {"mac": "mac_walk3_kernel<33, 7, true, 2, 1> grid=262144"}}
+    by = {"forward": 202e6, "mac": 337e6, "inverse": 219e6}
+    t = kernel_table(kms, ev, {"mac": "mac_walk3_kernel<33, 7, true, 2, 1>"}, entry, by, tiled_bytes(8192, 64, 256), 8 * 256)
+    assert t["mac"]["ms"] == 0.11 and t["mac"]["event_ms"] == 0.115 and t["mac"]["trace_us"] == 98.3
+    assert abs(t["mac"]["frac"] - 337e6 / 0.11e-3 / 8e12) < 1e-4            # the regression shows in the fraction
+    assert not hasattr(_bench(), "fit_trace_to_wall")

@@ -193,6 +193,67 @@ def test_hbm_rate_hook(engine):
         engine.hbm_rates(1024, 1)                          # below the 1 MiB floor: FE_ERR_PARAM
 
 
+def test_kernel_times_bound_to_the_dispatches():
+    """Profiling mode 2 (what bench.py's per-kernel `ms` and `frac` come from): a start / stop event bound to each dispatch.
+    The three kernel times of a call are positive, no longer than the event-to-event times of mode 1 (which hold a launch
+    boundary each), their sum fits inside the call's wall time; results are the same bits with profiling on or off; the
+    accumulators reset."""
+    import time
+    import torch
+    from folve_amd.capi import BatchPlan, FE_ASYNC, FE_DEVICE_PTRS
+    eng = fa.Engine(0)
+    size, S, T, C = 65536, 8, 32, 2
+    flt = fa.Filter(eng, C, C, size)
+    rng = np.random.default_rng(5)
+    for c in range(C):
+        flt.add(c, c, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))
+    flt.commit()
+    P = flt.block_size
+    streams = [flt.open_stream(T) for _ in range(S)]
+    xs = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
+    ys = [torch.empty_like(x) for x in xs]
+    torch.cuda.synchronize()
+    plan = BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S, FE_DEVICE_PTRS | FE_ASYNC)
+    plan.run(); eng.synchronize()
+    plain = [y.cpu().numpy().copy() for y in ys]
+    n = 40
+    for _ in range(5):
+        plan.run()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        plan.run()
+    eng.synchronize()
+    wall_ms = (time.perf_counter() - t0) / n * 1e3
+    eng.reset_profile()
+    eng.set_profiling(2)
+    for st in streams:
+        st.reset()
+    plan.run(); eng.synchronize()
+    for y, ref in zip(ys, plain):
+        assert np.array_equal(y.cpu().numpy(), ref)                 # the same kernels, the same bits
+    for _ in range(n - 1):                                           # more rounds than the ring of 32 event sets holds
+        plan.run()
+    k = eng.get_kernel_profile()
+    eng.set_profiling(1)
+    for _ in range(n):
+        plan.run()
+    eng.synchronize()
+    e = eng.get_profile()
+    eng.set_profiling(0)
+    kms = {r: v["ms"] / v["launches"] for r, v in k.items()}
+    ems = {r: v["ms"] / v["launches"] for r, v in e.items()}
+    assert all(v["launches"] == n for v in k.values()) and all(v["launches"] == n for v in e.values())
+    for r in kms:
+        assert 0.002 < kms[r] < 5.0, kms
+        assert kms[r] <= ems[r] * 1.05 + 0.001, (kms, ems)           # an event behind the kernel also holds the boundary
+    assert sum(kms.values()) <= wall_ms * 1.10 + 0.005, (kms, wall_ms)
+    eng.reset_profile()
+    assert all(v["launches"] == 0 and v["ms"] == 0.0 for v in eng.get_kernel_profile().values())
+    for s_ in streams:
+        s_.close()
+
+
 def test_benchmarked_shape_parity(engine, oracle):
     """bench.py's workload, kernel for kernel: 64 streams x 2 channels x 256 blocks per call through a
     262 144-tap 2-path filter, streams opened for 256-block calls, device-resident PCM, automatic form

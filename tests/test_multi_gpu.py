@@ -80,48 +80,77 @@ def test_an_open_file_moves_at_every_depth_and_position(tmp_path):
         assert c["moves"] == 1 and c["engine_changed"], c
 
 
-def test_bench_two_ranks_on_one_gpu():
-    env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+def run_bench(args, env, tmp_path, timeout=900, launcher=None):
+    """bench.py as the driver runs it (or under `launcher`): returns (the ONE stdout line parsed, the details file parsed).
+    The line must be the only JSON line, under 4 KB, and name the details file."""
+    details = str(tmp_path / "bench_details.json")
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + list(args) + ["--details", details]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout                                           # rank 0 only
+    assert len(lines) == 1, r.stdout                                           # rank 0 only, one line
+    assert len(lines[0]) < 4096, len(lines[0])                                 # the driver keeps an 8 KB tail (round 5's line was lost)
     out = json.loads(lines[0])
+    assert out["details"] == details
+    return out, json.load(open(details))
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29611"]
+    out, det = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16", "--no-cpu-baseline"],
+                         env, tmp_path, launcher=launcher)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
     assert out["config"]["streams_per_gpu"] == 8 and out["config"]["total_streams"] == 16
-    assert out["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]   # gpu = stream mod N
+    assert out["shards"] == {"rule": "gpu = stream mod N", "streams_per_rank": [8, 8], "first_of_rank": [0, 1]}
+    assert det["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]   # gpu = stream mod N
     assert out["parity_rms"] is not None and out["parity_rms"] <= 1e-5
-    assert out["value"] > 0
+    assert out["value"] > 0 and det["value"] == out["value"]
 
 
-def test_bench_gpus_2_launches_its_own_ranks():
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with NO launcher around it (what the driver's SCALE step may run): bench.py starts its two
     ranks as a child process itself, and the N = 2 line carries everything the N = 1 line does — roofline, cpu_baseline
     (timed by rank 0 after the process group is gone), shards.  Both ranks on device 0 over gloo: a one-GPU box."""
     env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "8",
-           "--blocks", "16", "--cpu-seconds", "2"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    out, det = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16", "--cpu-seconds", "2"], env, tmp_path)
     assert out["n_gpus"] == 2 and out["config"]["total_streams"] == 16 and out["value"] > 0
-    assert out["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]
+    assert det["shards"] == [[0, 2, 4, 6, 8, 10, 12, 14], [1, 3, 5, 7, 9, 11, 13, 15]]
     assert out["process_group"] == {"backend": "gloo", "world_size": 2, "forced_at_world_size_1": False}
-    assert out["stream_peaks"]["streams"] == 16 and 0.5 < out["stream_peaks"]["min_abs"] <= out["stream_peaks"]["max_abs"] < 20   # gathered over both ranks
-    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel_ms"] > 0 and out["roofline"]["frac_lower_bound"] > 0
+    sp = det["stream_peaks"]
+    assert sp["streams"] == 16 and 0.5 < sp["min_abs"] <= sp["max_abs"] < 20   # gathered over both ranks
+    assert out["roofline"]["bound"] in ("hbm", "valu") and out["roofline"]["kernel_ms"] > 0 and out["roofline"]["frac_lower_bound"] > 0
     cpu = out["cpu_baseline"]
     assert cpu and cpu["value"] > 0 and cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["sample"]
     assert out["parity_rms"] <= 1e-5
 
 
-def test_bench_cfg5_shape_eight_ranks_512_streams_on_one_gpu():
+def test_the_two_rank_line_of_the_benchmarked_shape_against_one_rank(tmp_path):
+    """The command the driver's SCALE step runs, `python3 bench.py --gpus 2 --steps 20 --warmup 5`, on a one-GPU box (both
+    ranks on device 0 over gloo): the line is small and complete (roofline, cpu_baseline, shards, process group), and the
+    job's aggregate rate agrees with the N = 1 line's measured in the same session on the same device — two ranks of 32
+    streams share the GPU that one rank of 64 streams has to itself, so value(N = 2) / 2 per rank = value(N = 1) / 2:
+    the sharded path (barriers, max over ranks, two engines) costs nothing beside the one-process path.  The pool's own
+    semantics: one processor per open file, whichever GPU it lands on (/root/reference/processor-pool.cc:48-91)."""
+    env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    (tmp_path / "n1").mkdir(); (tmp_path / "n2").mkdir()
+    common = ["--steps", "20", "--warmup", "5", "--no-extras", "--cpu-seconds", "2"]
+    one, _ = run_bench(["--gpus", "1"] + common, env, tmp_path / "n1")
+    two, det = run_bench(["--gpus", "2", "--streams", "32"] + common, env, tmp_path / "n2", timeout=1500)
+    assert two["n_gpus"] == 2 and two["config"]["total_streams"] == 64 and two["config"]["blocks_per_step"] == 256
+    assert two["process_group"]["world_size"] == 2 and two["shards"]["streams_per_rank"] == [32, 32]
+    assert two["roofline"]["kernel_ms"] > 0 and two["roofline"]["frac_lower_bound"] > 0 and two["cpu_baseline"]["value"] > 0
+    assert two["parity_rms"] <= 1e-5 and one["parity_rms"] <= 1e-5
+    per_rank_share = two["value"] / 2
+    assert abs(per_rank_share - one["value"] / 2) <= 0.10 * (one["value"] / 2), (one["value"], two["value"])
+
+
+def test_bench_cfg5_shape_eight_ranks_512_streams_on_one_gpu(tmp_path):
     """BASELINE.json configs[4] through bench.py itself: `python bench.py --gpus 8` — eight ranks x 64 streams x 256 blocks,
     cfg5's 512 streams sharded gpu = stream mod 8 — with all eight ranks on device 0 over gloo (a one-GPU box: the rate it
     prints is eight processes sharing one GPU and means nothing; what is checked is the launch, the sharding, the parity
@@ -129,36 +158,28 @@ def test_bench_cfg5_shape_eight_ranks_512_streams_on_one_gpu():
     env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    out, det = run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env, tmp_path, timeout=1500)
     assert out["n_gpus"] == 8 and out["scaling"] == "weak"
     assert out["config"]["streams_per_gpu"] == 64 and out["config"]["total_streams"] == 512 and out["config"]["blocks_per_step"] == 256
-    assert len(out["shards"]) == 8 and all(len(s) == 64 for s in out["shards"])
-    assert sorted(i for s in out["shards"] for i in s) == list(range(512)) and out["shards"][3][:3] == [3, 11, 19]
+    assert out["shards"]["streams_per_rank"] == [64] * 8 and out["shards"]["first_of_rank"] == list(range(8))
+    assert len(det["shards"]) == 8 and all(len(s) == 64 for s in det["shards"])
+    assert sorted(i for s in det["shards"] for i in s) == list(range(512)) and det["shards"][3][:3] == [3, 11, 19]
     assert out["process_group"] == {"backend": "gloo", "world_size": 8, "forced_at_world_size_1": False}
     assert out["parity_rms"] <= 1e-5 and out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
-    assert out["stream_peaks"]["streams"] == 512 and out["stream_peaks"]["min_abs"] > 0.5      # every stream's maximum arrived
+    assert det["stream_peaks"]["streams"] == 512 and det["stream_peaks"]["min_abs"] > 0.5      # every stream's maximum arrived
 
 
-def test_bench_rccl_branch_runs_on_one_gpu():
+def test_bench_rccl_branch_runs_on_one_gpu(tmp_path):
     """The RCCL branch of bench.py — init_process_group("nccl", device_id), the barriers around the timed region and the
     reductions of sharding.aggregate_throughput, beside the engine's private HIP streams — behind FOLVE_BENCH_FORCE_DIST=1
     at world size 1: everything of the N > 1 launch that one GPU can run."""
     env = dict(os.environ, FOLVE_BENCH_FORCE_DIST="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FOLVE_BENCH_BACKEND"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16",
-           "--no-cpu-baseline", "--no-extras"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out, det = run_bench(["--steps", "3", "--warmup", "1", "--streams", "8", "--blocks", "16", "--no-cpu-baseline", "--no-extras"], env, tmp_path)
     assert out["process_group"] == {"backend": "nccl", "world_size": 1, "forced_at_world_size_1": True}
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_rms"] <= 1e-5
-    assert out["stream_peaks"]["streams"] == 8 and out["stream_peaks"]["min_abs"] > 0.5       # (the gather's reduction ran over RCCL)
+    assert det["stream_peaks"]["streams"] == 8 and det["stream_peaks"]["min_abs"] > 0.5       # (the gather's reduction ran over RCCL)
 
 
 def test_harness_over_two_router_slots_with_numa_placement(tmp_path):

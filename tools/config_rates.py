@@ -2,7 +2,7 @@
 function).  Dev aid:  python tools/config_rates.py [blocks per call] [tune, e.g. mac_form=16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import measure_config
+from benchlib.configs import measure_config
 
 if __name__ == "__main__":
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
