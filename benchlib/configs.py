@@ -124,13 +124,18 @@ def measure_config(S, C, size, T, populated=None, steps=100, warmup=10, tune=Non
     for _ in range(warmup):
         plan.run()
     eng.synchronize()
-    watch = PowerWatch(dev)
     t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # socket power and shader clock while these launches run: the same loop for at least 0.3 s under the reader (the timed
+    # loop of a lone stream is over in 6 ms: no sample would fall into it)
+    watch = PowerWatch(dev)
     with watch:
-        for _ in range(steps):
+        for _ in range(max(steps, int(0.3 / max(dt, 1e-6)))):
             plan.run()
         eng.synchronize()
-    dt = (time.perf_counter() - t0) / steps
     kms, event_ms = profile_kernels(eng, plan.run, steps)
     launched = eng.last_kernels()
     out = {"kernels_launched": launched, "streams": S, "channels": C, "taps": size, "block": P, "partitions": K, "populated_partitions": flt.path_partitions(0, 0),

@@ -13,11 +13,11 @@ FE_HOST_PTRS, FE_DEVICE_PTRS, FE_ASYNC = 0, 1, 2
 FE_K_FORWARD, FE_K_MAC, FE_K_INVERSE, FE_K_COUNT = 0, 1, 2, 3
 FE_TUNE_FWD_RUN, FE_TUNE_INV_RUN, FE_TUNE_MAC_FORM, FE_TUNE_FFT_FORM, FE_TUNE_FAIL_NEXT, FE_TUNE_LANES = 0, 1, 2, 3, 4, 5
 FE_TUNE_WALK_LPB, FE_TUNE_WALK_TILES, FE_TUNE_DUPLEX_OUT, FE_TUNE_DUPLEX_CHUNK_MB, FE_TUNE_DUPLEX_MIN_MB = 6, 7, 8, 9, 10
-FE_TUNE_SPLIT, FE_TUNE_DUPLEX_CAP_MB, FE_TUNE_WALK_FMA = 11, 12, 13
+FE_TUNE_SPLIT, FE_TUNE_DUPLEX_CAP_MB, FE_TUNE_WALK_FMA, FE_TUNE_WALK_NT = 11, 12, 13, 14
 TUNE_KNOBS = {"fwd_run": FE_TUNE_FWD_RUN, "inv_run": FE_TUNE_INV_RUN, "mac_form": FE_TUNE_MAC_FORM,
               "fft_form": FE_TUNE_FFT_FORM, "fail_next": FE_TUNE_FAIL_NEXT, "lanes": FE_TUNE_LANES,
               "walk_lpb": FE_TUNE_WALK_LPB, "walk_tiles": FE_TUNE_WALK_TILES, "duplex_out": FE_TUNE_DUPLEX_OUT, "duplex_chunk_mb": FE_TUNE_DUPLEX_CHUNK_MB, "duplex_min_mb": FE_TUNE_DUPLEX_MIN_MB, "split": FE_TUNE_SPLIT, "duplex_cap_mb": FE_TUNE_DUPLEX_CAP_MB,
-              "walk_fma": FE_TUNE_WALK_FMA}
+              "walk_fma": FE_TUNE_WALK_FMA, "walk_nt": FE_TUNE_WALK_NT}
 KERNEL_NAMES = ("forward", "mac", "inverse")
 
 
@@ -95,6 +95,7 @@ ENGINE_SYMBOLS = [
     ("fe_engine_last_kernels", _i, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("fe_engine_hbm_rates", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
     ("fe_engine_hbm_rates2", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
+    ("fe_engine_hbm_rates3", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
 ]
 
 
@@ -205,6 +206,13 @@ class Engine:
         g = (C.c_double * 5)()
         _chk(lib().fe_engine_hbm_rates2(self.h, nbytes, reps, g), "fe_engine_hbm_rates2")
         return {"read": float(g[0]), "write": float(g[1]), "copy": float(g[2]), "write_regions": float(g[3]), "copy_regions": float(g[4])}
+
+    def hbm_rates3(self, nbytes=1 << 31, reps=20):
+        """hbm_rates2 plus "copy_best": the best float4 copy shape found on MI355X (non-temporal both ways, 4 KiB bursts)."""
+        g = (C.c_double * 6)()
+        _chk(lib().fe_engine_hbm_rates3(self.h, nbytes, reps, g), "fe_engine_hbm_rates3")
+        return {"read": float(g[0]), "write": float(g[1]), "copy": float(g[2]), "write_regions": float(g[3]), "copy_regions": float(g[4]),
+                "copy_best": float(g[5])}
 
     def close(self):
         if self.h:

@@ -1766,6 +1766,10 @@ int fe_engine_set_tuning(fe_engine* e, int knob, int value) {
             if (value != 0 && value != 3 && value != 4) return fail(FE_ERR_PARAM, "walk FMA form must be 0, 3 or 4");
             e->tuning.walk_fma = value;
             return FE_OK;
+        case FE_TUNE_WALK_NT:
+            if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "walk nt must be 0, 1 or 2");
+            e->tuning.walk_nt = value;
+            return FE_OK;
         case FE_TUNE_DUPLEX_OUT:
             if (value < 0 || value > 2) return fail(FE_ERR_PARAM, "duplex out must be 0, 1 or 2");
             e->duplex_out = value;
@@ -1875,6 +1879,7 @@ int fe_engine_get_kernel_profile(fe_engine* e, long long launches[FE_K_COUNT], d
 static int hbm_rates_n(fe_engine* e, size_t bytes, int reps, double* gbs, int modes);
 int fe_engine_hbm_rates(fe_engine* e, size_t bytes, int reps, double gbs[3]) { return hbm_rates_n(e, bytes, reps, gbs, 3); }
 int fe_engine_hbm_rates2(fe_engine* e, size_t bytes, int reps, double gbs[5]) { return hbm_rates_n(e, bytes, reps, gbs, 5); }
+int fe_engine_hbm_rates3(fe_engine* e, size_t bytes, int reps, double gbs[6]) { return hbm_rates_n(e, bytes, reps, gbs, 6); }
 static int hbm_rates_n(fe_engine* e, size_t bytes, int reps, double* gbs, int modes) {
     if (!e || !gbs || reps < 1 || bytes < ((size_t)1 << 20)) return fail(FE_ERR_PARAM, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
@@ -1897,7 +1902,7 @@ static int hbm_rates_n(fe_engine* e, size_t bytes, int reps, double* gbs, int mo
         if (rc == hipSuccess) rc = hipEventSynchronize(e1);
         float ms = 0.f;
         if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, e0, e1);
-        if (rc == hipSuccess) gbs[mode] = (mode == 2 || mode == 4 ? 2.0 : 1.0) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+        if (rc == hipSuccess) gbs[mode] = (mode == 2 || mode == 4 || mode == 5 ? 2.0 : 1.0) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
     }
     (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

@@ -245,6 +245,9 @@ FK_D float4 gld_u4_once(const void* base, unsigned off) {
     const v4f v = __builtin_nontemporal_load((const FK_GLOBAL v4f*)((const FK_GLOBAL char*)base + off));
     return float4{v.x, v.y, v.z, v.w};
 }
+FK_D void gst_u2_once(void* base, unsigned off, float2 v) {
+    __builtin_nontemporal_store(v2f{v.x, v.y}, (FK_GLOBAL v2f*)((FK_GLOBAL char*)base + off));
+}
 FK_D void gst_u4_once(void* base, unsigned off, float4 v) {
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (FK_GLOBAL v4f*)((FK_GLOBAL char*)base + off));
 }

@@ -63,6 +63,7 @@ struct Tuning {
     int walk_lpb = 0;       // K2 whole-call walk: lanes per bin (1, 2, 4) instead of the automatic choice
     int walk_tiles = 0;     // K2 whole-call walk: time tiles per call
     int walk_fma = 0;       // K2 whole-call walk: 3 = the three-FMA form (mac_walk3.hip), 4 = the four-FMA form, 0 = by shape
+    int walk_nt = 0;        // K2 three-FMA walk, 33 rows on one lane: rows with the non-temporal hint — 0 by the launch's bytes, 1 never, 2 always
     LaunchNames* names = nullptr;   // set per call: where the launchers note the kernels they chose
     hipEvent_t (*kev)[2] = nullptr; // set per call while profiling: per role (0 = K1, 1 = K2, 2 = K3) a start / stop event to bind to the dispatch
     // set per call: the only descriptor of a one-stream launch, readable by the HOST.  Every kernel then receives it
@@ -98,7 +99,8 @@ hipError_t launch_inverse(const StreamJob* jobs, int njobs, int max_blocks, cons
 // the same for xlane_swap16, out[256..511] the four registers after xlane_transpose4 of (10*i + lane/16).
 hipError_t launch_xlane_selftest(float* out512, hipStream_t st);
 // Measurement hook (bench.py): plain streaming kernels over `bytes` of `a` (and `b`), 16 bytes per lane —
-// mode 0 read a, 1 write b, 2 copy a -> b.  What this GPU's HBM delivers to ANY kernel, read and written apart.
+// mode 0 read a, 1 write b, 2 copy a -> b, 3 / 4 write / copy with every workgroup in its own region, 5 the best copy shape found
+// (non-temporal both ways, 4 KiB bursts per wave).  What this GPU's HBM delivers to ANY kernel, read and written apart.
 hipError_t launch_hbm_probe(int mode, const void* a, void* b, size_t bytes, hipStream_t st);
 struct FftTables { const float2* tw; const float2* twa; const float2* twb; const float2* twa2; const float2* twb2; };
 // K0: time-domain taps [ndata][K*P] -> Htmp [ndata][K][P] (scaled by 1/(2P)) -> G [ndata][K+1][P].

@@ -141,13 +141,19 @@ __device__ __forceinline__ void split_and_store(const float2* s, const float2 (&
         }
         // row is wave-uniform: the round's share of the address goes into the scalar base, and two
         // per-lane offsets (tid, NT - 1 - tid) serve all rounds
+#ifdef FOLVE_K1_NT_STORE                                       // experiment: the spectrum rows leave with the non-temporal hint
+#define FK_SPLIT_ST gst_u2_once
+#else
+#define FK_SPLIT_ST gst_u2
+#endif
         if (c == 0) {
-            gst_u2(row, (unsigned)k * 8u, r1);
-            gst_u2(row, (unsigned)k2 * 8u, r2);
+            FK_SPLIT_ST(row, (unsigned)k * 8u, r1);
+            FK_SPLIT_ST(row, (unsigned)k2 * 8u, r2);
         } else {
-            gst_u2(row + c * S::NT, (unsigned)tid * 8u, r1);
-            gst_u2(row + (P - c * S::NT - (S::NT - 1)), (unsigned)(S::NT - 1 - tid) * 8u, r2);
+            FK_SPLIT_ST(row + c * S::NT, (unsigned)tid * 8u, r1);
+            FK_SPLIT_ST(row + (P - c * S::NT - (S::NT - 1)), (unsigned)(S::NT - 1 - tid) * 8u, r2);
         }
+#undef FK_SPLIT_ST
         if constexpr (BATCH > 0) {
             // a compiler-level memory barrier: the next batch's LDS reads stay behind this batch's stores
             if ((c + 1) % BATCH == 0 && c + 1 < S::CNT) asm volatile("" ::: "memory");
@@ -2035,11 +2041,31 @@ __global__ __launch_bounds__(256) void hbm_copy_regions_kernel(const v4f* __rest
     v4f* __restrict__ pb = b + (size_t)blockIdx.x * per;
     for (size_t i = threadIdx.x; i < per; i += 256) pb[i] = pa[i];
 }
+// The best float4 copy found on this pool's MI355X boxes (tools/micro/copy_rate.hip, profiles/r06_copy_rate.txt: 5.87 - 5.99 TB/s
+// counting both directions; /opt/skills/guides/MI355X_MICROARCH.md:36 quotes 6.29): non-temporal loads AND stores, a read burst of
+// 4 KiB per wave followed by its write burst, grid-stride tiles.  The yardstick bench.py holds K1 / K2 / K3 against.
+__global__ __launch_bounds__(256) void hbm_copy_best_kernel(const v4f* __restrict__ a, v4f* __restrict__ b, size_t n) {
+    constexpr int U = 4;
+    const size_t tile = (size_t)256 * U, tiles = n / tile;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const v4f* p = a + t * tile + threadIdx.x;
+        v4f* q = b + t * tile + threadIdx.x;
+        v4f r[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) r[j] = __builtin_nontemporal_load(p + j * 256);
+#pragma unroll
+        for (int j = 0; j < U; ++j) __builtin_nontemporal_store(r[j], q + j * 256);
+    }
+}
 }  // namespace
 
 hipError_t launch_hbm_probe(int mode, const void* a, void* b, size_t bytes, hipStream_t st) {
     const size_t n = bytes / 16;
     dim3 grid(2048), block(256);                              // 8 workgroups per CU, grid-stride
+    if (mode == 5) {
+        hipLaunchKernelGGL(hbm_copy_best_kernel, dim3(256 * 12), block, 0, st, (const v4f*)a, (v4f*)b, n);
+        return hipGetLastError();
+    }
     if (mode == 0) hipLaunchKernelGGL(hbm_read_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);
     else if (mode == 1) hipLaunchKernelGGL(hbm_write_kernel, grid, block, 0, st, (v4f*)b, n);
     else if (mode == 2) hipLaunchKernelGGL(hbm_copy_kernel, grid, block, 0, st, (const v4f*)a, (v4f*)b, n);

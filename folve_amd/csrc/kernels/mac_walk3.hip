@@ -78,6 +78,14 @@ __device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool, u
         "v_cndmask_b32_dpp %1, %3, %1, vcc row_shr:1 row_mask:0xf bank_mask:0xf"
         : "+v"(mine.x), "+v"(mine.y) : "v"(leaving.x), "v"(leaving.y), "s"(heads) : "vcc");
 }
+// Inside the loop the mask stays in VCC from the loop's head on (the marker statement sets it once per round of W steps):
+// nothing between the head and the round's last hand-down writes VCC — the steps are VALU / SALU-on-SCC / VMEM only —
+// and tools/check_isa.py holds the built code to that (`vcc_writers_in_loop`).  One scalar instruction per step less.
+__device__ __forceinline__ void hand_down_vcc_live(v2f& mine, const v2f& leaving) {
+    asm volatile("v_cndmask_b32_dpp %0, %2, %0, vcc row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %1, %3, %1, vcc row_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(mine.x), "+v"(mine.y) : "v"(leaving.x), "v"(leaving.y));
+}
 // sum += its neighbour's (lane ^ 1 / lane ^ 2), every lane: the shift rides on the add's first operand.  (s_nop 1: a DPP
 // operand written by the VALU instruction in front needs two wait states, and inside an asm block nobody counts them.)
 template <int CTRL0, int CTRL1, int CTRL2, int CTRL3>
@@ -95,13 +103,18 @@ __device__ __forceinline__ void hand_down(v2f& mine, const v2f& leaving, bool he
 }
 #endif
 
-template <int KR, int D, bool PIN, int LPB = 1, int NP = 1>
 #ifndef FOLVE_W3_WG
 #define FOLVE_W3_WG 256          // threads per workgroup (the walk uses neither LDS nor barriers: the size only shapes dispatch and DRAM
                                  // locality).  Measured (-DFOLVE_W3_WG=512, tools/build_variant.sh): cfg3's K2 0.93 -> 1.02 ms, cfg4 the same
 #endif
-__global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8 : 0) <= 168) ? 3 : 2) * 256 / FOLVE_W3_WG) void mac_walk3_kernel(
-    JobRef jr, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
+#define FK_W3_BOUNDS __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LPB > 1 ? 8 : 0) <= 168) ? 3 : 2) * 256 / FOLVE_W3_WG)
+// NT: the walk's row loads AND its stores carry the non-temporal hint — for launches whose rows of X and Y are streams far
+// larger than the 256 MB Infinity Cache (cfg3: 2.4 GB in, 2.1 GB out).  Both or neither: a float4 copy on this GPU moves 5.9 -
+// 6.0 TB/s with the hint on both sides and 5.3 - 5.7 with it on one side or none (tools/micro/copy_rate.hip,
+// profiles/r06_copy_rate.txt), and so does the walk: cfg3's K2 0.889 -> 0.859 ms with both, 0.897 / 0.900 with only the
+// loads / only the stores (profiles/r06_ab_nt.txt).  A lone stream's Y fits the cache and K3 finds it there: plain.
+template <int KR, int D, bool PIN, int LPB, int NP, bool NT>
+__device__ __forceinline__ void walk3_body(const JobRef& jr, const FilterDev& f, float2* __restrict__ Y, int tiles, int tile_len) {
     constexpr int W = KR + D;
     constexpr int KRP = (KR + 1) / 2;                       // pairs of rows
     static_assert(W % 2 == 0, "a slot's parity must be its block's parity");
@@ -208,7 +221,8 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
         const unsigned rb = (unsigned)P * 8u;                // a row, in bytes
         const auto xres = make_rsrc(X, 0xffffffffu);
         auto issue = [&](v2f& dst, unsigned row_off) {
-            if constexpr (PIN) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff_x), "s"(xres), "s"(row_off) : "memory");
+            if constexpr (PIN && NT) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=&v"(dst) : "v"(voff_x), "s"(xres), "s"(row_off) : "memory");
+            else if constexpr (PIN) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff_x), "s"(xres), "s"(row_off) : "memory");
             else dst = *(const FK_GLOBAL v2f*)((const FK_GLOBAL char*)X + row_off + voff_x);
         };
         unsigned xo = (unsigned)ring_slot(job.slot0, tb, ring) * rb;       // the row the next load takes
@@ -216,11 +230,20 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
         // Past the tile's last block the walk stays on it (re-read from L2, never used; running on into the ring's next rows
         // would be D rows of HBM traffic per wavefront and call: 57 MB of cfg3's 4.6 GB).  Selects, not a branch: a branch that
         // is never taken costs a wavefront ~16 cycles, a scalar instruction ~3.4 (tools/micro/valu_rates.hip).
+        // ... where the walk's time is memory (one lane per bin, one path per output).  Where it is instruction issue
+        // (several lanes per bin, filter matrices: 84 % VALU issue, SQ counters) the two scalar instructions per step cost
+        // more than the few rows a tile reads past its end — any row of the ring is mapped memory —: no clamp there.
+#ifdef FOLVE_W3_CLAMP_ALL
+        constexpr bool CLAMP = true;
+#else
+        constexpr bool CLAMP = LPB == 1 && NP == 1;
+#endif
         const unsigned xlast = (unsigned)ring_slot(job.slot0, tb + nb - 1, ring) * rb;
         auto advance = [&]() {
             unsigned nx = xo + rb;
             nx = (nx == ring_bytes) ? 0u : nx;
-            xo = (xo == xlast) ? xo : nx;
+            if constexpr (CLAMP) xo = (xo == xlast) ? xo : nx;
+            else xo = nx;
         };
         // the first even step's carry: the odd rows' products of T(0), all from the history
         v2f carry;
@@ -254,7 +277,12 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
         unsigned voff_y = voff;
         int left = nb;                                       // steps to go, counted per group
         for (;;) {                                           // (nb >= 1)
+#if defined(FOLVE_W3_PLAIN_DPP) || defined(FOLVE_W3_VCC_PER_STEP)
             asm volatile("s_setprio 0");                     // (does nothing: marks the loop's head for tools/check_isa.py, whatever the block layout)
+#else
+            if constexpr (LPP > 1) asm volatile("s_setprio 0\n\ts_mov_b64 vcc, %0" : : "s"(heads) : "vcc");   // the marker, and the heads' mask for this round's hand-downs
+            else asm volatile("s_setprio 0");                // (does nothing: marks the loop's head for tools/check_isa.py, whatever the block layout)
+#endif
             const bool more = static_all<W / G>([&](auto gc) {
               static_for<G>([&](auto ic) {
                 constexpr int u = decltype(gc)::value * G + decltype(ic)::value;
@@ -273,7 +301,11 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #endif
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[un]) : "n"(N) : "memory");
                 }
+#if defined(FOLVE_W3_PLAIN_DPP) || defined(FOLVE_W3_VCC_PER_STEP)
                 if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head, heads);
+#else
+                if constexpr (LPP > 1) hand_down_vcc_live(w[un], w[(u + 1 + D) % W]);
+#endif
                 if constexpr (un % 2 == 0) sp[un / 2].x = add_ab(w[un]);
                 else sp[un / 2].y = add_ab(w[un]);
                 // Two (I, R) accumulators and two for T.  What decides the mix of compiler-generated and inline-asm arithmetic is
@@ -329,6 +361,37 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #define FK_W3_EVEN "v_pk_add_f32 %0, %2, %6 op_sel:[0,1] op_sel_hi:[0,1]\n\t"
 #define FK_W3_ODD "v_pk_add_f32 %0, %2, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
                 if constexpr (NIR == 2) ir[2] = ir[3] = v2f{0.f, 0.f};       // (operands of the asm below, not used by its two-accumulator form)
+#if !defined(FOLVE_W3_PLAIN_DPP) && !defined(FOLVE_W3_SUM_ANYWHERE)
+                // Several lanes per bin: the sum over the bin's lanes rides in the same block, on `sum` in a FIXED register pair
+                // (v[166:167]: an asm operand cannot name the halves of a pair, a physical register can) — as two scalar
+                // operands the allocator split the pair and moved a half out and back around the DPP adds in some
+                // instantiations (1.2 v_mov per step).  (s_nop 1: a DPP operand written by the VALU instruction in front needs
+                // two wait states.)
+#define FK_W3_ACROSS2 "\n\ts_nop 1\n\t"                                                             \
+    "v_add_f32_dpp v166, v166, v166 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"              \
+    "v_add_f32_dpp v167, v167, v167 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define FK_W3_ACROSS4 FK_W3_ACROSS2 "\n\ts_nop 1\n\t"                                               \
+    "v_add_f32_dpp v166, v166, v166 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"              \
+    "v_add_f32_dpp v167, v167, v167 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+#define FK_W3_FIXED(STEP, ACROSS)                                                                    \
+    asm("v_pk_add_f32 %1, %1, %4\n\t"                                                                \
+        "v_pk_add_f32 %2, %2, %5\n\t" STEP                                                           \
+        "v_pk_fma_f32 v[166:167], %1, %7, v[166:167] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"           \
+        "v_pk_fma_f32 v[166:167], %1, %7, v[166:167] op_sel:[0,1,0] op_sel_hi:[1,1,1]" ACROSS         \
+        : "=&{v[166:167]}"(sum), "+v"(ir[0]), "+v"(tt[0]) : "v"(ir[0]), "v"(ir[1]), "v"(tt[1]), "v"(carry), "v"(sel))
+                if constexpr (LPB >= 2 && NIR == 2) {
+                    if constexpr (u % 2 == 0) {
+                        if constexpr (LPB == 2) FK_W3_FIXED("v_pk_add_f32 v[166:167], %2, %6 op_sel:[0,1] op_sel_hi:[0,1]\n\t", FK_W3_ACROSS2);
+                        else FK_W3_FIXED("v_pk_add_f32 v[166:167], %2, %6 op_sel:[0,1] op_sel_hi:[0,1]\n\t", FK_W3_ACROSS4);
+                        carry = tt[0];
+                    } else {
+                        if constexpr (LPB == 2) FK_W3_FIXED("v_pk_add_f32 v[166:167], %2, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t", FK_W3_ACROSS2);
+                        else FK_W3_FIXED("v_pk_add_f32 v[166:167], %2, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t", FK_W3_ACROSS4);
+                    }
+                } else
+#undef FK_W3_ACROSS2
+#undef FK_W3_ACROSS4
+#endif
                 if constexpr (u % 2 == 0) {
                     if constexpr (NIR == 4)
                         asm(FK_W3_HEAD4 FK_W3_EVEN FK_W3_TAIL : "=&v"(sum), "+v"(ir[0]), "+v"(tt[0]), "+v"(ir[2])
@@ -348,7 +411,13 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #undef FK_W3_EVEN
 #undef FK_W3_ODD
 #undef FK_W3_TAIL
-#ifndef FOLVE_W3_PLAIN_DPP
+#undef FK_W3_FIXED
+#if !defined(FOLVE_W3_PLAIN_DPP) && !defined(FOLVE_W3_SUM_ANYWHERE)
+                if constexpr (NIR != 2) {                              // (the two-accumulator form has summed across its lanes above)
+                    if constexpr (LPB >= 2) add_across<1, 0, 3, 2>(sum);
+                    if constexpr (LPB >= 4) add_across<2, 3, 0, 1>(sum);
+                }
+#elif !defined(FOLVE_W3_PLAIN_DPP)
                 if constexpr (LPB >= 2) add_across<1, 0, 3, 2>(sum);   // the group's partial sums: every lane ends up with the total
                 if constexpr (LPB >= 4) add_across<2, 3, 0, 1>(sum);
 #else
@@ -362,7 +431,8 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
 #ifdef FOLVE_W3_NOSTORE                                      // what-if build (tools/build_variant.sh): the walk without its stores
                 asm volatile("" : : "v"(sum));
 #else
-                if constexpr (PIN) asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(sum), "v"(voff_y), "s"(yres) : "memory");
+                if constexpr (PIN && NT) asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen nt" : : "v"(sum), "v"(voff_y), "s"(yres) : "memory");
+                else if constexpr (PIN) asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(sum), "v"(voff_y), "s"(yres) : "memory");
                 else if (voff_y < (unsigned)nb * rb) *(FK_GLOBAL v2f*)((FK_GLOBAL char*)ybase + voff_y) = sum;
 #endif
                 voff_y += rb;
@@ -378,6 +448,16 @@ __global__ __launch_bounds__(FOLVE_W3_WG, ((3 * (KR + D) + 3 * KR + 1 + 24 + (LP
     }
 }
 
+template <int KR, int D, bool PIN, int LPB = 1, int NP = 1>
+__global__ FK_W3_BOUNDS void mac_walk3_kernel(JobRef jr, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
+    walk3_body<KR, D, PIN, LPB, NP, false>(jr, f, Y, tiles, tile_len);
+}
+// the streaming form (rows with the non-temporal hint), a kernel of its own name so that a profile tells the two apart
+template <int KR, int D, bool PIN, int LPB = 1, int NP = 1>
+__global__ FK_W3_BOUNDS void mac_walk3_nt_kernel(JobRef jr, FilterDev f, float2* __restrict__ Y, int tiles, int tile_len) {
+    walk3_body<KR, D, PIN, LPB, NP, true>(jr, f, Y, tiles, tile_len);
+}
+
 template <int KR, int D, int LPB, int NP = 1>
 hipError_t launch3(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, const WalkShape& w, const Tuning& tn, hipStream_t st) {
     dim3 grid(f.P * LPB / FOLVE_W3_WG, f.cout * w.tiles, njobs), block(FOLVE_W3_WG);
@@ -386,6 +466,16 @@ hipError_t launch3(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, c
 #else
     constexpr bool kPin = true;
 #endif
+    // the streaming form where this launch's rows of Y (and as many of X) cannot stay in the 256 MB Infinity Cache anyway
+    if constexpr (KR == 33 && LPB == 1 && NP == 1 && kPin) {
+        const unsigned long long y_bytes = (unsigned long long)njobs * f.cout * w.tiles * w.tile_len * f.P * 8ull;
+#ifndef FOLVE_W3_NO_NT
+        if (tn.walk_nt == 2 || (tn.walk_nt == 0 && y_bytes > (192ull << 20))) {
+            FK_LAUNCH(1, (mac_walk3_nt_kernel<KR, D, kPin, LPB, NP>), grid, block, st, jr, f, Y, w.tiles, w.tile_len);
+            return hipGetLastError();
+        }
+#endif
+    }
     FK_LAUNCH(1, (mac_walk3_kernel<KR, D, kPin, LPB, NP>), grid, block, st, jr, f, Y, w.tiles, w.tile_len);
     return hipGetLastError();
 }

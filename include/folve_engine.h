@@ -201,6 +201,8 @@ enum {
                               0 / 1 never (the default: measured slower than one chain), 2 .. 8 tiles; calls longer than the stream's
                               run-ahead depth (several launch rounds) are not split */
     FE_TUNE_WALK_FMA = 13, /* K2 whole-call walk: 3 = three multiply-adds per complex one (kernels/mac_walk3.hip), 4 = four, 0 = by shape */
+    FE_TUNE_WALK_NT = 14,  /* K2 three-FMA walk of 33 rows on one lane per bin: its row loads and stores carry the non-temporal hint
+                              0 = where the launch's rows of Y exceed 192 MB (they cannot stay in the 256 MB Infinity Cache), 1 = never, 2 = always */
     FE_TUNE_LANES = 5      /* fe_batch_submit: 1 = every batch on the engine's own HIP stream, 0 / 2 = two lanes (batches of different
                               streams overlap: one reads its PCM over the bus while the other writes its results back) */
 };
@@ -235,6 +237,10 @@ int fe_engine_hbm_rates(fe_engine *e, size_t bytes, int reps, double gbs[3]);
  * gbs[3] writing, gbs[4] copying (bytes read + written).  On MI355X stores care (5.6 - 6.1 TB/s against 4.0 - 5.1), loads do
  * not (tools/micro/write_rate.hip). */
 int fe_engine_hbm_rates2(fe_engine *e, size_t bytes, int reps, double gbs[5]);
+/* ... plus gbs[5]: the best float4 copy shape found on MI355X (tools/micro/copy_rate.hip: non-temporal loads and stores, a 4 KiB
+ * read burst per wave then its write burst; 5.9 - 6.0 TB/s counting both directions where the plain copies give 4.7 - 5.2;
+ * /opt/skills/guides/MI355X_MICROARCH.md:36 quotes 6.29) — the copy yardstick of bench.py's roofline.measured_hbm. */
+int fe_engine_hbm_rates3(fe_engine *e, size_t bytes, int reps, double gbs[6]);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ def _rms(a):
 def tuned(engine):
     """The session engine with every knob back on automatic afterwards."""
     yield engine
-    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0, split=0, duplex_cap_mb=0, walk_fma=0)
+    engine.set_tuning(fwd_run=0, inv_run=0, mac_form=0, fft_form=0, fail_next=0, walk_lpb=0, walk_tiles=0, split=0, duplex_cap_mb=0, walk_fma=0, walk_nt=0)
 
 
 def test_xlane_exchange_semantics(engine):
@@ -189,6 +189,8 @@ def test_hbm_rate_hook(engine):
     r2 = engine.hbm_rates2(256 << 20, 5)
     assert set(r2) == {"read", "write", "copy", "write_regions", "copy_regions"}
     assert all(500.0 < v < 20000.0 for v in r2.values()), r2
+    r3 = engine.hbm_rates3(256 << 20, 5)
+    assert set(r3) == set(r2) | {"copy_best"} and 500.0 < r3["copy_best"] < 20000.0, r3
     with pytest.raises(Exception):
         engine.hbm_rates(1024, 1)                          # below the 1 MiB floor: FE_ERR_PARAM
 
@@ -277,6 +279,10 @@ def test_benchmarked_shape_parity(engine, oracle):
     from folve_amd.capi import BatchPlan, FE_DEVICE_PTRS
     torch.cuda.synchronize()                 # (the engine has its own HIP stream: torch's fills come first)
     BatchPlan(streams, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], lens, FE_DEVICE_PTRS).run()
+    k = engine.last_kernels()
+    # the benchmarked launch's own kernels: the stereo walkers and the walk's streaming form (2.1 GB of Y: non-temporal rows)
+    assert k["forward"].startswith("forward_walker_kernel<13") and k["inverse"].startswith("inverse_walker_kernel<13"), k
+    assert k["mac"].replace("false", "true") == "mac_walk3_nt_kernel<33, 7, true, 1, 1>", k
     x2 = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
     y2 = [torch.zeros(T * P, C, device="cuda") for _ in range(S)]
     torch.cuda.synchronize()
@@ -587,6 +593,31 @@ def test_walk_window_ladder_in_both_forms(tuned, oracle, size, window):
             assert tuned.last_kernels()["mac"].replace("false", "true") == name, tuned.last_kernels()   # (false: the NO_PIN fallback build)
             for s in range(S):
                 assert _rms(ys[s] - ref[s]) <= 2e-6, (fma, tiles, s)
+
+
+def test_the_streaming_form_of_the_walk_is_the_same_arithmetic(tuned, oracle):
+    """`mac_walk3_nt_kernel<33, 7, true, 1, 1>`: the 33-row walk whose row loads and stores carry the non-temporal hint —
+    chosen by itself where a launch's rows of Y exceed 192 MB (cfg3's batch: test_benchmarked_shape_parity), pinned here on a
+    small batch (FE_TUNE_WALK_NT = 2) and held against the plain form (= 1): the same instructions but for a cache-policy
+    bit, so the same bits; several tile counts, ragged tails."""
+    size = 262144
+    rng = np.random.default_rng(77)
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    _, flt, _ = make_pair(tuned, oracle, 2, 2, size, paths)
+    P, K = flt.block_size, flt.partitions
+    T, S = K + 9, 3
+    xs = [rng.uniform(-1, 1, (T * P - 777 * s - 1, 2)).astype(np.float32) for s in range(S)]
+    for tiles in (1, 3):
+        outs = {}
+        for nt, name in ((1, "mac_walk3_kernel<33, 7, true, 1, 1>"), (2, "mac_walk3_nt_kernel<33, 7, true, 1, 1>")):
+            tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=tiles, walk_fma=3, walk_nt=nt)
+            outs[nt] = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+            assert tuned.last_kernels()["mac"].replace("false", "true") == name, tuned.last_kernels()
+        for s in range(S):
+            assert np.array_equal(outs[1][s], outs[2][s]), (tiles, s)
+    tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=0, walk_fma=3, walk_nt=0)      # by itself: a batch this small stays plain
+    fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
+    assert tuned.last_kernels()["mac"].startswith("mac_walk3_kernel<33,")
 
 
 @pytest.mark.parametrize("size,block", [(256, 256), (300, 512), (700, 1024), (1500, 2048), (3000, 4096), (4097, 8192)])

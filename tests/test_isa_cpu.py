@@ -58,3 +58,12 @@ def test_the_checker_sees_what_it_is_there_for():
         assert any("v_mov_b32" in p for p in check_isa.check_walk_loop(name, body[:idx + 1] + ["v_mov_b32_e32 v250, v%d" % dst] + body[idx + 1:]))
         assert any("expected (KR + D)" in p for p in check_isa.check_walk_loop(name, body[:idx + 1] + ["global_load_dwordx2 v[252:253], v0, s[0:1]"] + body[idx + 1:]))
         assert any("scratch_load" in p for p in check_isa.check_walk_loop(name, body[:idx + 1] + ["scratch_load_dword v250, off, s0"] + body[idx + 1:]))
+        # the hand-downs of a multi-lane walk read the heads' mask from VCC, set once at the loop's head: a VCC writer among
+        # the steps (here a VOPC compare in front of a hand-down) must be reported, and so must a head that does not set it
+        dpp = [i for i, l in enumerate(body) if l.startswith("v_cndmask_b32_dpp") and l in loop]
+        if dpp and "mac_walk3_kernel" in name:
+            assert any("touches vcc" in p for p in check_isa.check_walk_loop(name, body[:dpp[3]] + ["v_cmp_eq_u32_e32 vcc, v250, v251"] + body[dpp[3]:]))
+            assert any("touches vcc" in p for p in check_isa.check_walk_loop(name, body[:dpp[3]] + ["s_and_b64 vcc, exec, s[6:7]"] + body[dpp[3]:]))
+            head = next(i for i, l in enumerate(body) if l.startswith("s_setprio"))
+            assert body[head + 1].startswith("s_mov_b64 vcc")
+            assert any("does not set it" in p for p in check_isa.check_walk_loop(name, body[:head + 1] + body[head + 2:]))

@@ -244,10 +244,32 @@ def check_walk_loop(name, body):
                         problems.append("%s: `%s` uses v%d before the load into it was waited for" % (name, ins.split("//")[0].strip(), r))
     if loads != kr + d or stores != kr + d:
         problems.append("%s: %d loads and %d stores in the walk loop, %d each expected (KR + D)" % (name, loads, stores, kr + d))
+    problems += vcc_writers_in_loop(name, loop)
     return sorted(set(problems))
 
 
-WALK_NAMES = ("mac_walk_kernel", "mac_walk3_kernel")   # kernels.hip (four FMAs per complex MAC), mac_walk3.hip (three)
+def vcc_writers_in_loop(name, loop):
+    """mac_walk3.hip's hand-down (`v_cndmask_b32_dpp .., vcc`, several lanes per path) reads the lane sets' heads from VCC, which
+    the loop's head sets ONCE per round (`s_mov_b64 vcc` right behind the marker).  Between that and the round's last
+    hand-down nothing may write VCC: no other instruction naming vcc, no VOP2 / VOPC form that writes it implicitly."""
+    users = [i for i, ins in enumerate(loop) if split_operands(ins)[0] == "v_cndmask_b32_dpp" and re.search(r"\bvcc\b", ins)]
+    if not users:
+        return []
+    problems = []
+    mn0, ops0 = split_operands(loop[0])
+    if not (mn0 == "s_mov_b64" and ops0 and ops0[0] == "vcc"):
+        problems.append("%s: the walk loop's hand-downs read vcc but the loop's head does not set it (`%s`)" % (name, loop[0].split("//")[0].strip()))
+    for ins in loop[1:users[-1]]:
+        mn, ops = split_operands(ins)
+        if mn == "v_cndmask_b32_dpp":
+            continue
+        implicit = (mn.startswith("v_cmp") and mn.endswith("_e32")) or (mn.endswith("_e32") and ("_co_" in mn or mn.startswith(("v_addc", "v_subb", "v_div_fmas"))))
+        if implicit or re.search(r"\bvcc(_lo|_hi)?\b", ins.split("//")[0]):
+            problems.append("%s: `%s` touches vcc between the loop's head and its last hand-down" % (name, ins.split("//")[0].strip()))
+    return problems
+
+
+WALK_NAMES = ("mac_walk_kernel", "mac_walk3_kernel", "mac_walk3_nt_kernel")   # kernels.hip (four FMAs per complex MAC), mac_walk3.hip (three; _nt: rows with the non-temporal hint)
 
 
 def default_objects():

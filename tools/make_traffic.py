@@ -17,7 +17,7 @@ summ = json.load(open(os.path.join(ROOT, "profiles", tag + "_summary.json")))
 ROLES = {
     # (a lone stereo stream's call of fewer than 512 blocks takes the per-channel general kernels: the last names)
     "T": {"forward": ("forward_walker_kernel", "forward_chpair_kernel", "forward_dual_kernel", "forward_kernel"),
-          "mac": ("mac_walk3_kernel", "mac_walk_kernel", "mac_slide_kernel"),
+          "mac": ("mac_walk3_nt_kernel", "mac_walk3_kernel", "mac_walk_kernel", "mac_slide_kernel"),
           "inverse": ("inverse_walker_kernel", "inverse_chpair_kernel", "inverse_kernel")},
     "1": {"forward": ("forward_kernel",), "mac": ("mac_kernel<1>",), "inverse": ("inverse_kernel",)},
 }

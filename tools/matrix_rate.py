@@ -19,9 +19,9 @@ def run(full, S=64, T=256, size=262144, tune=None):
         xs = [torch.rand(T * P, 2, device="cuda") * 2 - 1 for _ in range(S)]; ys = [torch.empty_like(x) for x in xs]
     plan = BatchPlan(st, [x.data_ptr() for x in xs], [y.data_ptr() for y in ys], [T * P] * S, FE_DEVICE_PTRS | FE_ASYNC)
     for _ in range(5): plan.run()
-    eng.synchronize(); eng.set_profiling(True); eng.reset_profile()
+    eng.synchronize(); eng.reset_profile(); eng.set_profiling(2)
     for _ in range(30): plan.run()
-    eng.synchronize(); p = eng.get_profile(); eng.set_profiling(False)
+    eng.synchronize(); p = eng.get_kernel_profile(); eng.set_profiling(0)
     k = {n: v["ms"] / v["launches"] for n, v in p.items()}
     print("full matrix" if full else "diagonal   ", {n: round(v, 3) for n, v in k.items()}, "%.1f Gsamples/s" % (S * T * P * 2 / sum(k.values()) / 1e6))
 
