@@ -47,6 +47,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int kJobSlots = 64;    // (rounds whose descriptors may be in flight at once: a pipeline of more chunks than slots blocks its caller)
+constexpr int kSlabJobs = 128;   // descriptors a slot holds without an allocation of its own (a combined batch of 128 streams)
 
 // Frees a temporary device allocation on every exit path.
 struct DevTmp {
@@ -117,6 +118,9 @@ struct fe_engine {
     fk::StreamJob* jobs_host[kJobSlots] = {};
     fk::StreamJob* jobs_dev[kJobSlots] = {};
     size_t jobs_cap[kJobSlots] = {};
+    bool jobs_own[kJobSlots] = {};       // the slot outgrew its share of the slabs and has allocations of its own
+    fk::StreamJob* jobs_slab_host = nullptr;   // kJobSlots x kSlabJobs descriptors, page-locked / on the device: allocated with the engine,
+    fk::StreamJob* jobs_slab_dev = nullptr;    // so that no launch round of a warm-up pays an allocation (hipMalloc can synchronise the device)
     hipEvent_t jobs_ev[kJobSlots] = {};
     bool jobs_ev_pending[kJobSlots] = {};
     int jobs_next = 0;
@@ -324,37 +328,43 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     int rc = ensure_bytes(e, (void**)&L.Y, &L.Y_bytes, (size_t)yunits * P * sizeof(float2), st);
     if (rc) return rc;
 
-    // upload the descriptors through a rotating pinned buffer; a slot is reused only after the round
-    // that read it has finished (its event is recorded behind that round's last kernel)
-    const int slot = e->jobs_next;
-    e->jobs_next = (e->jobs_next + 1) % kJobSlots;
-    if (e->jobs_ev_pending[slot]) {
-        HIP_TRY(hipEventSynchronize(e->jobs_ev[slot]));
-        e->jobs_ev_pending[slot] = false;
-    }
-    const size_t bytes = jobs.size() * sizeof(fk::StreamJob);
-    if (e->jobs_cap[slot] < bytes) {
-        if (e->jobs_host[slot]) HIP_TRY(hipHostFree(e->jobs_host[slot]));
-        if (e->jobs_dev[slot]) HIP_TRY(hipFree(e->jobs_dev[slot]));    // (its last reader has finished: the slot's event, above)
-        e->jobs_host[slot] = nullptr; e->jobs_dev[slot] = nullptr; e->jobs_cap[slot] = 0;
-        const size_t cap = std::max<size_t>(bytes * 2, 64 * sizeof(fk::StreamJob));
-        HIP_TRY(hipHostMalloc((void**)&e->jobs_host[slot], cap, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void**)&e->jobs_dev[slot], cap));
-        e->jobs_cap[slot] = cap;
-    }
-    memcpy(e->jobs_host[slot], jobs.data(), bytes);
-    // Small launches (the single-block path, and the combined one-block calls of many file threads, whose
-    // PCM crosses the bus anyway) read their descriptors straight from the page-locked buffer — no upload
-    // command in front of K1 (10 - 15 us of copy-engine latency per round); large ones upload them once
-    // (thousands of workgroups should not each fetch a descriptor over the bus).
-    // A launch of ONE stream carries its descriptor among the kernel arguments (Tuning::one_job): nothing to upload, nothing
-    // to fetch.
-    const fk::StreamJob* dj = e->jobs_dev[slot];
+    // A launch of ONE stream carries its descriptor among the kernel arguments (Tuning::one_job, copied at launch): nothing to
+    // upload, nothing to fetch, no slot.  Several streams: the descriptors go through a rotating pinned buffer; a slot is
+    // reused only after the round that read it has finished (its event is recorded behind that round's last kernel).
+    // Small launches (the combined one-block calls of many file threads, whose PCM crosses the bus anyway) read their
+    // descriptors straight from the page-locked buffer — no upload command in front of K1 (10 - 15 us of copy-engine
+    // latency per round); large ones upload them once (thousands of workgroups should not each fetch a descriptor over
+    // the bus).
     const int nj = (int)jobs.size();
-    if (nj == 1 || (long long)nj * max_blocks <= (e->host_io ? 256 : 16)) {
-        dj = e->jobs_host[slot];
-    } else {
-        HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+    const fk::StreamJob* dj = nullptr;
+    int slot = -1;
+    if (nj > 1) {
+        slot = e->jobs_next;
+        e->jobs_next = (e->jobs_next + 1) % kJobSlots;
+        if (e->jobs_ev_pending[slot]) {
+            HIP_TRY(hipEventSynchronize(e->jobs_ev[slot]));
+            e->jobs_ev_pending[slot] = false;
+        }
+        const size_t bytes = jobs.size() * sizeof(fk::StreamJob);
+        if (e->jobs_cap[slot] < bytes) {                        // more streams than a slot's share of the slabs holds
+            if (e->jobs_own[slot]) {
+                if (e->jobs_host[slot]) HIP_TRY(hipHostFree(e->jobs_host[slot]));
+                if (e->jobs_dev[slot]) HIP_TRY(hipFree(e->jobs_dev[slot]));    // (its last reader has finished: the slot's event, above)
+            }
+            e->jobs_host[slot] = nullptr; e->jobs_dev[slot] = nullptr; e->jobs_cap[slot] = 0;
+            e->jobs_own[slot] = true;
+            const size_t cap = bytes * 2;
+            HIP_TRY(hipHostMalloc((void**)&e->jobs_host[slot], cap, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**)&e->jobs_dev[slot], cap));
+            e->jobs_cap[slot] = cap;
+        }
+        memcpy(e->jobs_host[slot], jobs.data(), bytes);
+        if ((long long)nj * max_blocks <= (e->host_io ? 256 : 16)) {
+            dj = e->jobs_host[slot];
+        } else {
+            dj = e->jobs_dev[slot];
+            HIP_TRY(hipMemcpyAsync(e->jobs_dev[slot], e->jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+        }
     }
 
     const bool prof = e->profiling == 1, kprof = e->profiling == 2;
@@ -366,7 +376,7 @@ int launch_round(fe_engine* e, fe_filter* f, std::vector<Item>& items, bool* any
     tn.in_resident = e->in_resident;
     tn.max_ring = max_ring;
     if (want_block_peaks) tn.inv_run = 1;      // K3's walker: one block per workgroup, whose maxima are the block's
-    tn.one_job = nj == 1 ? e->jobs_host[slot] : nullptr;
+    tn.one_job = nj == 1 ? &jobs[0] : nullptr;
     tn.names = &e->last_names;
     int kset = -1;
     if (kprof) {
@@ -1137,6 +1147,18 @@ int fe_engine_create(int device, void* hip_stream, fe_engine** out) {
             return fail(FE_ERR_DEVICE, "hipEventCreate failed");
         }
     }
+    // every descriptor slot's buffers up front, carved out of two slabs
+    if (hipHostMalloc((void**)&e->jobs_slab_host, (size_t)kJobSlots * kSlabJobs * sizeof(fk::StreamJob), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&e->jobs_slab_dev, (size_t)kJobSlots * kSlabJobs * sizeof(fk::StreamJob)) != hipSuccess) {
+        (void)hipGetLastError();
+        delete e;
+        return fail(FE_ERR_ALLOC, "descriptor buffers: allocation failed");
+    }
+    for (int i = 0; i < kJobSlots; ++i) {
+        e->jobs_host[i] = e->jobs_slab_host + (size_t)i * kSlabJobs;
+        e->jobs_dev[i] = e->jobs_slab_dev + (size_t)i * kSlabJobs;
+        e->jobs_cap[i] = kSlabJobs * sizeof(fk::StreamJob);
+    }
     for (int i = 0; i < 4; ++i) {
         if (hipEventCreate(&e->pev[i]) != hipSuccess) { delete e; return fail(FE_ERR_DEVICE, "hipEventCreate failed"); }
     }
@@ -1178,10 +1200,12 @@ static void engine_release(fe_engine* e) {
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     for (int i = 0; i < kJobSlots; ++i) {
-        if (e->jobs_host[i]) (void)hipHostFree(e->jobs_host[i]);
-        if (e->jobs_dev[i]) (void)hipFree(e->jobs_dev[i]);
+        if (e->jobs_own[i] && e->jobs_host[i]) (void)hipHostFree(e->jobs_host[i]);
+        if (e->jobs_own[i] && e->jobs_dev[i]) (void)hipFree(e->jobs_dev[i]);
         if (e->jobs_ev[i]) (void)hipEventDestroy(e->jobs_ev[i]);
     }
+    if (e->jobs_slab_host) (void)hipHostFree(e->jobs_slab_host);
+    if (e->jobs_slab_dev) (void)hipFree(e->jobs_slab_dev);
     for (int i = 0; i < 4; ++i) if (e->pev[i]) (void)hipEventDestroy(e->pev[i]);
     for (auto& set : e->kev)
         for (auto& role : set)

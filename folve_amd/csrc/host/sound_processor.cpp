@@ -45,6 +45,11 @@ const int kDefaultRunAhead = 64;
 // 64-channel stream is 2 MB; 64 of them twice over would pin 256 MB per open file).  Stereo and 8-channel streams at
 // the default depth stay below it (8 and 32 MB).
 const size_t kRingBudgetBytes = static_cast<size_t>(64) << 20;
+// The input history an open file keeps so that it can move to another GPU (2K + 2 blocks, pageable, touched only where a
+// block would otherwise be overwritten while it still counts): up to what the reference's own limits give — MAXSIZE = 2^20
+// taps (K = 128) on MAXINP = 64 channels (zita-config.h:61, zita-fconfig.cc:49-55): 258 blocks x 8192 frames x 64 channels.
+// (It was the ring's 64 MB until round 6: a 16-channel K = 128 file fell back to silence on a GPU failure.)
+const size_t kHistoryBudgetBytes = static_cast<size_t>(258) * 8192 * 64 * sizeof(float);
 }  // namespace
 
 void SoundProcessor::SetDevicePeaks(bool on) { g_device_peaks.store(on); }
@@ -135,9 +140,12 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     // The stream's delay line is sized for the longest call this processor will make: its run-ahead depth
     // (one block per call is the reference's contract and what depth 1 gives).
     int run_depth = RunAheadForBlock(zita.fragm);
+    // (read ONCE per processor: the run-ahead depth, the chunk layout and the history all follow from this one answer — a
+    // SetSurvival() from another thread between two reads would size the arena for one layout and use the other)
+    const bool keep_history = SurvivalWanted();
     {
         const size_t in = static_cast<size_t>(zita.fragm) * zita.ninp, out = static_cast<size_t>(zita.fragm) * zita.nout;
-        const size_t block_bytes = (zita.ninp == zita.nout && !SurvivalWanted() ? in : in + out) * sizeof(float);     // (ChunkFloats, below)
+        const size_t block_bytes = (zita.ninp == zita.nout && !keep_history ? in : in + out) * sizeof(float);     // (ChunkFloats, below)
         const size_t fit = block_bytes ? kRingBudgetBytes / (2 * block_bytes) : static_cast<size_t>(run_depth);
         if (fit < static_cast<size_t>(run_depth)) run_depth = static_cast<int>(std::max<size_t>(fit, 1));
     }
@@ -152,9 +160,9 @@ SoundProcessor* SoundProcessor::CreateOnReserved(fe_engine* engine, const std::s
     if (NumaPlacement()) {
         // page-locked pages land where the allocating thread runs: next to the GPU that will read them
         ScopedDeviceAffinity near_gpu(fe_engine_device(engine));
-        return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files, samplerate, channels);
+        return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files, samplerate, channels, keep_history);
     }
-    return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files, samplerate, channels);
+    return new SoundProcessor(zita, config_file, stream, run_depth, impulse_files, samplerate, channels, keep_history);
 }
 
 // The block buffer (`buffer_`, sound-processor.cc:62-63: fragm * max(ninp, nout) floats, reused in
@@ -183,14 +191,15 @@ static size_t ChunkFloats(const ZitaConfig& c, int depth, bool in_place) {
 }
 
 SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg, fe_stream* stream, int run_depth,
-                               const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels)
+                               const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels,
+                               bool keep_history)
     : zita_config_(config), config_file_(cfg), config_file_timestamp_(GetModificationTime(cfg)), impulse_files_(impulse_files),
       samplerate_(samplerate), channels_(channels), engine_(config.engine),
       stream_(stream), hist_(NULL), hist_cap_(0), hist_k_(0), blocks_fed_(0), moves_(0),
       run_depth_(run_depth),
-      in_place_(config.ninp == config.nout && !SurvivalWanted()),
+      in_place_(config.ninp == config.nout && !keep_history),
       buffer_floats_(static_cast<size_t>(config.fragm) * std::max(config.ninp, config.nout)),
-      arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth, config.ninp == config.nout && !SurvivalWanted())),
+      arena_floats_(buffer_floats_ + 2 * ChunkFloats(config, run_depth, config.ninp == config.nout && !keep_history)),
       buffer_(AllocBlockBuffer(arena_floats_, &buffer_pinned_)),
       cur_(NULL), ahead_(NULL), ring_block_(NULL), tail_(NULL), tail_frames_(0), source_short_(false), depth_next_(1),
       input_pos_(0), output_pos_(0), max_out_value_observed_(0.0), max_abs_value_observed_(0.0), ok_(true),
@@ -214,11 +223,11 @@ SoundProcessor::SoundProcessor(const ZitaConfig& config, const std::string& cfg,
     // the call's own input.  A run-ahead chunk's input stays where it is (its output has its own half of the chunk), so the
     // ring only ever takes what would otherwise be overwritten while still needed: single blocks (computed in place), chunks
     // shorter than K (the ramp, a file's end) and the tail of a long chunk whose buffer is about to be re-used early.
-    if (SurvivalWanted()) {
+    if (keep_history) {
         hist_k_ = config.fragm > 0 ? static_cast<int>((static_cast<long long>(config.size) + config.fragm - 1) / config.fragm) : 0;
         const long long cap = 2LL * hist_k_ + 2;
         const size_t bytes = static_cast<size_t>(cap) * config.fragm * config.ninp * sizeof(float);
-        if (hist_k_ > 0 && bytes <= kRingBudgetBytes) {
+        if (hist_k_ > 0 && bytes <= kHistoryBudgetBytes) {
             hist_ = new (std::nothrow) float[bytes / sizeof(float)];
             if (hist_) {
                 hist_cap_ = static_cast<int>(cap);
@@ -364,6 +373,14 @@ const float* SoundProcessor::BlockInput(long long b) const {
 // front of them the hist_k_ blocks before.
 bool SoundProcessor::MoveToAnotherGpu(long long first, int blocks, long long frames, float* out) {
     if (!hist_ || blocks <= 0 || first + blocks != blocks_fed_) return false;
+    // The other GPU's filter is looked up under this processor's (configuration, mtime): if the configuration or one of its
+    // impulse files has been edited since the file was opened, that lookup would parse the NEW content — other taps in the
+    // middle of a file, cached under the old key.  The taps this stream runs on exist nowhere but on the failed GPU: no move.
+    if (!ConfigStillUpToDate()) {
+        Logf("Processor %p: %s (or an impulse file of it) changed since this file was opened: the stream cannot move to another GPU",
+             static_cast<void*>(this), config_file_.c_str());
+        return false;
+    }
     DeviceRouter* router = DeviceRouter::Default();
     const int P = zita_config_.fragm;
     const size_t bf = static_cast<size_t>(P) * input_channels();

@@ -155,7 +155,8 @@ private:
         bool holds = false;             // in[] still holds the input of blocks [first, first + blocks) (it has not been read into since)
     };
     SoundProcessor(const ZitaConfig& config, const std::string& cfg_file, fe_stream* stream, int run_depth,
-                   const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels);
+                   const std::vector<std::pair<std::string, time_t>>& impulse_files, int samplerate, int channels,
+                   bool keep_history);
     void Process();
     bool ReadChunk(FrameSource* in, Chunk* c);    // true if the chunk holds at least one whole block
     void SubmitChunk(Chunk* c);

@@ -80,6 +80,26 @@ def test_an_open_file_moves_at_every_depth_and_position(tmp_path):
         assert c["moves"] == 1 and c["engine_changed"], c
 
 
+def test_a_file_beyond_the_old_history_budget_moves_and_a_stale_one_does_not(tmp_path):
+    """VERDICT r05 weak #10 and ADVICE r05: (a) a 16-channel K = 128 file (135 MB of input history, beyond the 64 MB the
+    history was budgeted with) loses its GPU at block 150 and moves — equal to its closed form, no silent block; (b) a file
+    whose configuration was edited while it was open does NOT move (the other GPU would get the new taps): silence,
+    ok() == false, and the next open gets the new configuration.  tests/survive_big_worker.py, a fresh process."""
+    env = dict(os.environ, FOLVE_AMD_DEVICES="0,0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "survive_big_worker.py"), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("SURVIVE_BIG_JSON ")][-1][len("SURVIVE_BIG_JSON "):])
+    big = out["big"]
+    assert big["history_bytes"] > (64 << 20) and big["partitions"] == 128
+    assert big["moves"] == 1 and big["engine_changed"] and big["ok"] == 1 and big["silent_blocks"] == 0, big
+    assert big["rms"] <= 1e-5 and big["max_err"] <= 1e-4 and big["peak_err"] <= 1e-6, big
+    st = out["stale"]
+    assert st["moves"] == 0 and st["ok"] == 0 and not st["config_up_to_date"], st
+    assert 10 <= st["first_bad_block"] <= 18 and st["tail_is_silence"], st          # (up to two run-ahead chunks of 4 were already computed)
+    assert st["next_open_gain_err"] <= 1e-6, st
+
+
 def run_bench(args, env, tmp_path, timeout=900, launcher=None):
     """bench.py as the driver runs it (or under `launcher`): returns (the ONE stdout line parsed, the details file parsed).
     The line must be the only JSON line, under 4 KB, and name the details file."""

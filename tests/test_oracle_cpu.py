@@ -182,7 +182,7 @@ def test_committed_traffic_table_is_consistent():
                 # since round 4 a stereo launch of fewer than 512 (block, stream) units takes the per-channel general kernels
                 fwd, inv = "forward_kernel<13>", "inverse_kernel<13>"
             assert e["kernels"]["forward"].startswith(fwd)
-            assert e["kernels"]["mac"].startswith(("mac_walk3_kernel", "mac_walk_kernel", "mac_slide_kernel"))
+            assert e["kernels"]["mac"].startswith(("mac_walk3_nt_kernel", "mac_walk3_kernel", "mac_walk_kernel", "mac_slide_kernel"))
             assert e["kernels"]["inverse"].startswith(inv)
             # bytes / time: a physically possible HBM rate
             for role in family:

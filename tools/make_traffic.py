@@ -44,7 +44,7 @@ tj["_comment"] = ("HBM bytes per launch from rocprofv3 PMC passes over `python b
                   "mac_kernel<1> (16-byte loads: 277 MB of X rows + the 4.3 MB filter, counter 282 MB), the K3 walker "
                   "(8-byte loads: every Y row once = 537 MB, counter 514 MB) and K1's spectra stores (8-byte: 537 MB, WRITE_SIZE "
                   "513 MB): exact to 1 % for 16-byte accesses, 4-5 % low for 8-byte ones.  avg_ns: kernel-trace averages of the "
-                  "same launches; bench.py uses an entry only while its own HIP-event times agree with them (15 %).")
+                  "same launches; bench.py uses an entry only for the same kernels (by name) while its own dispatch times agree with them (15 - 20 %).")
 for mode, blocks in ((("T", T), ("1", 1)) if "--run-ahead-only" not in sys.argv else (("T", T),)):
     entry = {"profile": tag, "bytes": {}, "avg_ns": {}, "read": {}, "write": {}, "kernels": {}}
     for role, names in ROLES[mode].items():

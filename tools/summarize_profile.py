@@ -19,7 +19,7 @@ res = {"kernel_trace": {}, "kernel_stats": {}, "pmc": {}}
 
 def short(name):
     for k in ("forward_dual_kernel", "make_g_kernel", "forward_walker_kernel", "inverse_walker_kernel", "forward_chpair_kernel",
-              "inverse_chpair_kernel", "forward_pair_kernel", "inverse_pair_kernel", "mac_slide_kernel", "mac_walk3_kernel", "mac_walk_kernel",
+              "inverse_chpair_kernel", "forward_pair_kernel", "inverse_pair_kernel", "mac_slide_kernel", "mac_walk3_nt_kernel", "mac_walk3_kernel", "mac_walk_kernel",
               "mac_small_kernel", "forward_kernel", "mac_kernel", "inverse_kernel", "filter_kernel"):
         if k in name:
             t = name.split(k)[1].split(">")[0].strip("<")
@@ -67,4 +67,12 @@ for key, w in res["pmc"].get("WRITE_SIZE", {}).items():
         wr = w["avg_KiB_per_dispatch"] * 1024
         hbm[key] = {"hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr}
 res["hbm_per_dispatch"] = hbm
+# (tools/profile.sh deletes csv files over 3 MB before the results travel back: a long --only-config run's kernel_trace.csv
+# can be among them.  Its kernels ran on ONE grid each, so the stats csv's per-kernel averages are the same figures.)
+for key in hbm:
+    name = key.split(" grid=")[0]
+    if key not in res["kernel_trace"] and name in res["kernel_stats"] and not any(k.startswith(name + " grid=") for k in res["kernel_trace"]):
+        st = res["kernel_stats"][name]
+        res["kernel_trace"][key] = {"dispatches": st["calls"], "avg_ns": st["avg_ns"], "min_ns": st["min_ns"], "max_ns": st["max_ns"],
+                                    "source": "kernel_stats.csv of the same trace run (one grid per kernel)"}
 print(json.dumps(res, indent=1))
