@@ -1,7 +1,7 @@
 """Dev aid: wall time per call of the lone-stream configurations (cfg1, cfg2, cfg4), asynchronous back-to-back calls."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import measure_config
+from benchlib.configs import measure_config
 for name, kw in (("cfg1", dict(S=1, C=2, size=65536, T=323)), ("cfg2", dict(S=1, C=2, size=204800, T=256, populated=178193)),
                  ("cfg4", dict(S=1, C=8, size=524288, T=256)), ("cfg4 x1024", dict(S=1, C=8, size=524288, T=1024))):
     for rep in range(2):

@@ -3,7 +3,7 @@ launch shape?  The same number of (block, channel) units as stereo streams (whol
 and with the per-pair non-walking kernels."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import measure_config
+from benchlib.configs import measure_config
 
 for name, S, C, T, tune in (("4 stereo streams x 256", 4, 2, 256, None), ("1 x 8ch x 256 (walkers per pair)", 1, 8, 256, None),
                             ("1 x 8ch x 256 (fft_form 3: chpair kernels)", 1, 8, 256, {"fft_form": 3}),
