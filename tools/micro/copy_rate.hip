@@ -88,5 +88,23 @@ int main() {
     block<8>(a, b, n, e0, e1);
     block<16>(a, b, n, e0, e1);
     printf("best: %.2f TB/s (%s) = %.3f of 8 TB/s; MI355X_MICROARCH.md:36 quotes 6.29\n", best, best_what, best / 8.0f);
+    // The same copy against its FOOTPRINT: the best shape (U = 4, non-temporal both ways, grid-stride, 12 workgroups per CU) and
+    // the plain own-regions shape over buffers of 128 MiB .. 8 GiB each (the engine's cfg3 batch touches ~11 GB per step).
+    CK(hipFree(a)); CK(hipFree(b));
+    printf("# footprint sweep: MiB per buffer | best shape TB/s | plain own-regions TB/s | best shape, source and destination halves of ONE allocation\n");
+    for (size_t mib : {128, 256, 512, 1024, 2048, 4096, 8192}) {
+        const size_t by = mib << 20, nn = by / 16;
+        v4f *x, *y, *z;
+        if (hipMalloc(&x, by) != hipSuccess || hipMalloc(&y, by) != hipSuccess || hipMalloc(&z, 2 * by) != hipSuccess) { printf("%5zu: allocation failed\n", mib); break; }
+        CK(hipMemset(x, 1, by)); CK(hipMemset(y, 0, by)); CK(hipMemset(z, 1, 2 * by));
+        printf("%5zu |", mib);
+        run<4, true, true, false>(x, y, nn, 12, e0, e1);
+        printf(" |");
+        run<4, false, false, true>(x, y, nn, 8, e0, e1);
+        printf(" |");
+        run<4, true, true, false>(z, z + nn, nn, 12, e0, e1);
+        printf("\n");
+        CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(z));
+    }
     return 0;
 }
