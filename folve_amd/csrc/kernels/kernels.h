@@ -63,7 +63,7 @@ struct Tuning {
     int walk_lpb = 0;       // K2 whole-call walk: lanes per bin (1, 2, 4) instead of the automatic choice
     int walk_tiles = 0;     // K2 whole-call walk: time tiles per call
     int walk_fma = 0;       // K2 whole-call walk: 3 = the three-FMA form (mac_walk3.hip), 4 = the four-FMA form, 0 = by shape
-    int walk_nt = 0;        // K2 three-FMA walk, 33 rows on one lane: rows with the non-temporal hint — 0 by the launch's bytes, 1 never, 2 always
+    int walk_nt = 0;        // K2 three-FMA walk on one lane per bin: rows with the non-temporal hint — 0 by the launch's bytes, 1 never, 2 always
     LaunchNames* names = nullptr;   // set per call: where the launchers note the kernels they chose
     hipEvent_t (*kev)[2] = nullptr; // set per call while profiling: per role (0 = K1, 1 = K2, 2 = K3) a start / stop event to bind to the dispatch
     // set per call: the only descriptor of a one-stream launch, readable by the HOST.  Every kernel then receives it

@@ -467,7 +467,7 @@ hipError_t launch3(const JobRef& jr, int njobs, const FilterDev& f, float2* Y, c
     constexpr bool kPin = true;
 #endif
     // the streaming form where this launch's rows of Y (and as many of X) cannot stay in the 256 MB Infinity Cache anyway
-    if constexpr (KR == 33 && LPB == 1 && NP == 1 && kPin) {
+    if constexpr (LPB == 1 && NP == 1 && kPin) {                     // (every rung of the one-lane ladder: their time is memory)
         const unsigned long long y_bytes = (unsigned long long)njobs * f.cout * w.tiles * w.tile_len * f.P * 8ull;
 #ifndef FOLVE_W3_NO_NT
         if (tn.walk_nt == 2 || (tn.walk_nt == 0 && y_bytes > (192ull << 20))) {

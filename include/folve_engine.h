@@ -201,7 +201,7 @@ enum {
                               0 / 1 never (the default: measured slower than one chain), 2 .. 8 tiles; calls longer than the stream's
                               run-ahead depth (several launch rounds) are not split */
     FE_TUNE_WALK_FMA = 13, /* K2 whole-call walk: 3 = three multiply-adds per complex one (kernels/mac_walk3.hip), 4 = four, 0 = by shape */
-    FE_TUNE_WALK_NT = 14,  /* K2 three-FMA walk of 33 rows on one lane per bin: its row loads and stores carry the non-temporal hint
+    FE_TUNE_WALK_NT = 14,  /* K2 three-FMA walk on one lane per bin (any rung of its window ladder): its row loads and stores carry the non-temporal hint
                               0 = where the launch's rows of Y exceed 192 MB (they cannot stay in the 256 MB Infinity Cache), 1 = never, 2 = always */
     FE_TUNE_LANES = 5      /* fe_batch_submit: 1 = every batch on the engine's own HIP stream, 0 / 2 = two lanes (batches of different
                               streams overlap: one reads its PCM over the bus while the other writes its results back) */

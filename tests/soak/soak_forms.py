@@ -32,16 +32,17 @@ for c in range(cases):
     outs = {}
     runlen = int(rng.choice([1, 2, 3, 4, 8, 16, 32]))
     lpb, tiles = int(rng.choice([0, 1, 2, 4])), int(rng.choice([0, 1, 2, 3, 7]))       # the walk's lanes per bin and time tiles
-    base = dict(walk_lpb=0, walk_tiles=0, walk_fma=0)
+    base = dict(walk_lpb=0, walk_tiles=0, walk_fma=0, walk_nt=0)
     for name, knobs in (("general", dict(mac_form=1, fft_form=1)), ("walk", dict(mac_form=100, fft_form=2, fwd_run=runlen, inv_run=runlen, walk_lpb=lpb, walk_tiles=tiles, walk_fma=3)),
                         ("walk4", dict(mac_form=100, fft_form=2, fwd_run=runlen, inv_run=runlen, walk_lpb=lpb, walk_tiles=tiles, walk_fma=4)),   # (the four-FMA form of the walk)
+                        ("walknt", dict(mac_form=100, fft_form=2, fwd_run=runlen, inv_run=runlen, walk_lpb=1, walk_tiles=tiles, walk_fma=3, walk_nt=2)),   # (the streaming form: every one-lane rung has one)
                         ("slide16", dict(mac_form=16, fft_form=2, fwd_run=0, inv_run=0)), ("auto", dict(mac_form=0, fft_form=0, fwd_run=0, inv_run=0))):
         eng.set_tuning(**dict(base, **knobs))
         st = [flt.open_stream(maxb) for _ in range(S)]
         outs[name] = [fa.batch_process(st, call) for call in calls]
-    eng.set_tuning(mac_form=0, fft_form=0, fwd_run=0, inv_run=0, walk_lpb=0, walk_tiles=0, walk_fma=0)
+    eng.set_tuning(mac_form=0, fft_form=0, fwd_run=0, inv_run=0, walk_lpb=0, walk_tiles=0, walk_fma=0, walk_nt=0)
     worst = 0.0
-    for name in ("walk", "walk4", "slide16", "auto"):
+    for name in ("walk", "walk4", "walknt", "slide16", "auto"):
         for a, b in zip(outs["general"], outs[name]):
             for x, y in zip(a, b):
                 if x.size:

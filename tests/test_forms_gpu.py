@@ -618,6 +618,17 @@ def test_the_streaming_form_of_the_walk_is_the_same_arithmetic(tuned, oracle):
     tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=0, walk_fma=3, walk_nt=0)      # by itself: a batch this small stays plain
     fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
     assert tuned.last_kernels()["mac"].startswith("mac_walk3_kernel<33,")
+    # every rung of the one-lane ladder has the streaming form (a big batch through a SHORT filter is memory-bound too)
+    size = 65536
+    paths = {(c, c): [(0, (rng.standard_normal(size) / np.sqrt(size)).astype(np.float32))] for c in range(2)}
+    _, flt9, _ = make_pair(tuned, oracle, 2, 2, size, paths)
+    xs9 = [rng.uniform(-1, 1, (21 * P - 5, 2)).astype(np.float32) for _ in range(2)]
+    outs = {}
+    for nt, name in ((1, "mac_walk3_kernel<9, 7, true, 1, 1>"), (2, "mac_walk3_nt_kernel<9, 7, true, 1, 1>")):
+        tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=2, walk_fma=3, walk_nt=nt)
+        outs[nt] = fa.batch_process([flt9.open_stream(21) for _ in range(2)], xs9)
+        assert tuned.last_kernels()["mac"].replace("false", "true") == name, tuned.last_kernels()
+    assert all(np.array_equal(a, b) for a, b in zip(outs[1], outs[2]))
 
 
 @pytest.mark.parametrize("size,block", [(256, 256), (300, 512), (700, 1024), (1500, 2048), (3000, 4096), (4097, 8192)])
