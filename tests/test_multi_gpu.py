@@ -115,6 +115,36 @@ def run_bench(args, env, tmp_path, timeout=900, launcher=None):
     return out, json.load(open(details))
 
 
+def test_the_line_the_driver_records(tmp_path):
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5`, every leg on — the command behind BENCH_rNN.json.  Round 5's line
+    of this command was 23.9 KB and came back unparsed; it must be ONE line under 4 KB that carries the contract's keys,
+    `roofline` (this run's kernel time, a fraction of a roof) and `cpu_baseline`, with one small entry per other
+    configuration; the per-kernel tables live in the details file, whose kernel times fit inside their calls."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FOLVE_BENCH_DEVICE", "FOLVE_BENCH_BACKEND", "FOLVE_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    out, det = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "4", "--skip", "drop_in"], env, tmp_path, timeout=1200)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in out, k
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1 and out["unit"] == "Msamples/s" and out["dtype"] == "f32"
+    assert abs(out["value"] - 64 * 256 * 8192 * 2 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * out["value"]     # value IS samples / time
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "valu") and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["kernel_ms"] > 0
+    assert rf["kernel_name"].startswith("mac_walk3_nt_kernel<33,") and 0.3 < rf["frac_lower_bound"] < 1.0
+    assert rf["frac"] is None or (0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["traffic"] / (rf["kernel_ms"] * 1e-3) / 8e12) < 2e-3)
+    assert sum(rf["kernels_ms"].values()) <= out["ms_per_step"] * 1.02                       # dispatch times fit inside the step
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"] and cb["one_core"]["value"] > 0
+    assert set(out["configs"]) == {"cfg1", "cfg2", "cfg4", "matrix"}
+    for name, c in out["configs"].items():
+        assert c["parity_rms"] <= 1e-5 and c["msamples_per_s"] > 0 and 0.2 < c["path_frac"] < 1.0, (name, c)
+        d = det["configs"][name]
+        assert d["kernels_sum_ms"] <= d["ms_per_call"] * 1.02, (name, d["kernels_sum_ms"], d["ms_per_call"])
+        for k in d["roofline"]["kernels"].values():
+            assert k["ms"] > 0 and (k["event_ms"] is None or k["ms"] <= k["event_ms"] * 1.10 + 0.002), k    # an event behind the kernel holds the boundary too
+    assert det["roofline"]["all_kernels"] and det["steady_state"]["steps"] == 400 and det["roofline_streaming"]["frac"] > 0.3
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, FOLVE_BENCH_DEVICE="0", FOLVE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
