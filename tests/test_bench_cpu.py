@@ -250,3 +250,32 @@ def test_kernel_times_in_the_tables_are_this_runs():
     assert t["mac"]["ms"] == 0.11 and t["mac"]["event_ms"] == 0.115 and t["mac"]["trace_us"] == 98.3
     assert abs(t["mac"]["frac"] - 337e6 / 0.11e-3 / 8e12) < 1e-4            # the regression shows in the fraction
     assert not hasattr(_bench(), "fit_trace_to_wall")
+
+
+def test_profile_summary_tells_the_streaming_walk_apart_and_survives_a_missing_trace(tmp_path):
+    """tools/summarize_profile.py on a synthetic rocprofv3 output: `mac_walk3_nt_kernel` is a kernel of its own (not folded
+    into `mac_walk3_kernel`), FETCH_SIZE is doubled (gfx950, MI355X_MICROARCH.md), and when the per-dispatch trace csv is
+    missing (tools/profile.sh deletes csv files over 3 MB) the stats csv's averages of the same run stand in, marked as such."""
+    import json
+    import subprocess
+    import sys
+    nt = "void fk::(anonymous namespace)::mac_walk3_nt_kernel<33, 7, true, 1, 1>(fk::(anonymous namespace)::JobRef, fk::FilterDev, HIP_vector_type<float, 2u>*, int, int)"
+    pl = "void fk::(anonymous namespace)::mac_walk3_kernel<26, 8, true, 1, 1>(fk::(anonymous namespace)::JobRef, fk::FilterDev, HIP_vector_type<float, 2u>*, int, int)"
+    d = tmp_path / "prof"
+    (d / "trace" / "r").mkdir(parents=True)
+    (d / "pmc_FETCH_SIZE" / "r").mkdir(parents=True)
+    (d / "pmc_WRITE_SIZE" / "r").mkdir(parents=True)
+    (d / "trace" / "r" / "1_kernel_stats.csv").write_text(
+        '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+        '"%s",10,8870000,887000.0,60.0,880000,890000,100.0\n"%s",20,322000,16100.0,2.0,15000,17000,100.0\n' % (nt, pl))
+    (d / "trace" / "r" / "1_kernel_trace.csv").write_text(                       # only the nt kernel's dispatches survived
+        '"Kernel_Name","Grid_Size","Start_Timestamp","End_Timestamp"\n' + "".join('"%s",1048576,%d,%d\n' % (nt, 1000 * i, 1000 * i + 887) for i in range(10)))
+    for c, kib in (("FETCH_SIZE", 1000.0), ("WRITE_SIZE", 2000.0)):
+        (d / ("pmc_" + c) / "r" / "2_counter_collection.csv").write_text(
+            '"Kernel_Name","Grid_Size","Counter_Name","Counter_Value"\n' +
+            "".join('"%s",%d,"%s",%f\n' % (k, g, c, kib) for k, g in ((nt, 1048576), (pl, 131072)) for _ in range(3)))
+    out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), str(d)], text=True))
+    knt, kpl = "mac_walk3_nt_kernel<33, 7, true, 1, 1> grid=1048576", "mac_walk3_kernel<26, 8, true, 1, 1> grid=131072"
+    assert out["kernel_trace"][knt]["avg_ns"] == 887 and out["kernel_trace"][knt]["dispatches"] == 10
+    assert out["kernel_trace"][kpl]["avg_ns"] == 16100.0 and "kernel_stats.csv" in out["kernel_trace"][kpl]["source"]
+    assert out["hbm_per_dispatch"][knt] == {"hbm_read_bytes_corrected": 2048000.0, "hbm_write_bytes": 2048000.0, "hbm_bytes": 4096000.0}
