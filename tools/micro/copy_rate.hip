@@ -106,5 +106,25 @@ int main() {
         printf("\n");
         CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(z));
     }
+    // Is the fall with the footprint the Infinity Cache no longer holding what the previous pass left?  The SAME 1 GiB per pass,
+    // best shape, (a) the same slice every pass, (b) a different 1 GiB slice of 8 GiB buffers every pass (each slice comes round
+    // again after 16 GiB of other traffic: touched once, as far as any cache can tell).
+    {
+        const size_t slice = (size_t)1 << 30, nn = slice / 16;
+        v4f *x, *y;
+        if (hipMalloc(&x, 8 * slice) == hipSuccess && hipMalloc(&y, 8 * slice) == hipSuccess) {
+            CK(hipMemset(x, 1, 8 * slice)); CK(hipMemset(y, 0, 8 * slice));
+            for (int rolling = 0; rolling < 2; ++rolling) {
+                for (int i = 0; i < 8; ++i) hipLaunchKernelGGL((copyk<4, true, true, false>), dim3(256 * 12), dim3(256), 0, 0, x + (rolling ? i : 0) * nn, y + (rolling ? i : 0) * nn, nn);
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 16; ++i) hipLaunchKernelGGL((copyk<4, true, true, false>), dim3(256 * 12), dim3(256), 0, 0, x + (rolling ? i % 8 : 0) * nn, y + (rolling ? i % 8 : 0) * nn, nn);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("1 GiB per pass, best shape, %s: %.2f TB/s\n", rolling ? "a different slice of 8 GiB every pass (touched once)" : "the same slice every pass", 2.0 * slice * 16 / (ms * 1e-3) / 1e12);
+            }
+            CK(hipFree(x)); CK(hipFree(y));
+        }
+    }
     return 0;
 }
