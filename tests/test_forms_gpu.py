@@ -615,6 +615,9 @@ def test_the_streaming_form_of_the_walk_is_the_same_arithmetic(tuned, oracle):
             assert tuned.last_kernels()["mac"].replace("false", "true") == name, tuned.last_kernels()
         for s in range(S):
             assert np.array_equal(outs[1][s], outs[2][s]), (tiles, s)
+    for bad in (-1, 3):
+        with pytest.raises(fa.FolveError):
+            tuned.set_tuning(walk_nt=bad)                  # FE_ERR_PARAM: 0 (by the launch's bytes), 1 (never), 2 (always)
     tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=0, walk_fma=3, walk_nt=0)      # by itself: a batch this small stays plain
     fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
     assert tuned.last_kernels()["mac"].startswith("mac_walk3_kernel<33,")
