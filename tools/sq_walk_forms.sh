@@ -21,7 +21,7 @@ for f in glob.glob("$OUT/raw_${shape}_$fma/p*/**/*counter_collection.csv", recur
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         key = None
-        for k in ("mac_walk3_kernel", "mac_walk_kernel"):
+        for k in ("mac_walk3_nt_kernel", "mac_walk3_kernel", "mac_walk_kernel"):
             if k in n and key is None: key = k
         if not key: continue
         a = acc[key][row["Counter_Name"]]
