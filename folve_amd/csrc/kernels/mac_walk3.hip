@@ -280,7 +280,9 @@ __device__ __forceinline__ void walk3_body(const JobRef& jr, const FilterDev& f,
 #if defined(FOLVE_W3_PLAIN_DPP) || defined(FOLVE_W3_VCC_PER_STEP)
             asm volatile("s_setprio 0");                     // (does nothing: marks the loop's head for tools/check_isa.py, whatever the block layout)
 #else
-            if constexpr (LPP > 1) asm volatile("s_setprio 0\n\ts_mov_b64 vcc, %0" : : "s"(heads) : "vcc");   // the marker, and the heads' mask for this round's hand-downs
+            // (only in the pinned build, whose loop is VALU / SALU-on-SCC / VMEM by hand: with compiler-scheduled accesses the
+            // range check of the store is a v_cmp into VCC — the NO_PIN fallback sets the mask per hand-down)
+            if constexpr (LPP > 1 && PIN) asm volatile("s_setprio 0\n\ts_mov_b64 vcc, %0" : : "s"(heads) : "vcc");   // the marker, and the heads' mask for this round's hand-downs
             else asm volatile("s_setprio 0");                // (does nothing: marks the loop's head for tools/check_isa.py, whatever the block layout)
 #endif
             const bool more = static_all<W / G>([&](auto gc) {
@@ -304,7 +306,8 @@ __device__ __forceinline__ void walk3_body(const JobRef& jr, const FilterDev& f,
 #if defined(FOLVE_W3_PLAIN_DPP) || defined(FOLVE_W3_VCC_PER_STEP)
                 if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head, heads);
 #else
-                if constexpr (LPP > 1) hand_down_vcc_live(w[un], w[(u + 1 + D) % W]);
+                if constexpr (LPP > 1 && PIN) hand_down_vcc_live(w[un], w[(u + 1 + D) % W]);
+                else if constexpr (LPP > 1) hand_down(w[un], w[(u + 1 + D) % W], head, heads);
 #endif
                 if constexpr (un % 2 == 0) sp[un / 2].x = add_ab(w[un]);
                 else sp[un / 2].y = add_ab(w[un]);

@@ -21,6 +21,16 @@ def _rms(a):
     return float(np.sqrt(np.mean(a * a)))
 
 
+def _walk_name(got):
+    """The launched K2 kernel's name as the pinned build spells it.  The NO_PIN fallback build (-DFOLVE_WALK_NO_PIN: loads and
+    stores left to the compiler) has `false` for PIN and no streaming form — the non-temporal hint rides on pinned asm."""
+    return got.replace("false", "true")
+
+
+def _is_fallback_build(got):
+    return ", false," in got
+
+
 @pytest.fixture
 def tuned(engine):
     """The session engine with every knob back on automatic afterwards."""
@@ -282,7 +292,7 @@ def test_benchmarked_shape_parity(engine, oracle):
     k = engine.last_kernels()
     # the benchmarked launch's own kernels: the stereo walkers and the walk's streaming form (2.1 GB of Y: non-temporal rows)
     assert k["forward"].startswith("forward_walker_kernel<13") and k["inverse"].startswith("inverse_walker_kernel<13"), k
-    assert k["mac"].replace("false", "true") == "mac_walk3_nt_kernel<33, 7, true, 1, 1>", k
+    assert _walk_name(k["mac"]) == ("mac_walk3_kernel<33, 7, true, 1, 1>" if _is_fallback_build(k["mac"]) else "mac_walk3_nt_kernel<33, 7, true, 1, 1>"), k
     x2 = [torch.rand(T * P, C, device="cuda") * 2 - 1 for _ in range(S)]
     y2 = [torch.zeros(T * P, C, device="cuda") for _ in range(S)]
     torch.cuda.synchronize()
@@ -565,10 +575,10 @@ def test_walk_window_for_a_short_filter_matrix(tuned, oracle):
     _, flt1, _ = make_pair(tuned, oracle, 2, 2, size, diag)
     tuned.set_tuning(mac_form=100, walk_fma=4, walk_lpb=1)
     fa.batch_process([flt1.open_stream(T) for _ in range(S)], xs)
-    assert tuned.last_kernels()["mac"] == "mac_walk_kernel<13, 7, true, 4, 1, 1>", tuned.last_kernels()
+    assert _walk_name(tuned.last_kernels()["mac"]) == "mac_walk_kernel<13, 7, true, 4, 1, 1>", tuned.last_kernels()
     tuned.set_tuning(mac_form=100, walk_fma=3, walk_lpb=1)
     fa.batch_process([flt1.open_stream(T) for _ in range(S)], xs)
-    assert tuned.last_kernels()["mac"] == "mac_walk3_kernel<13, 7, true, 1, 1>", tuned.last_kernels()
+    assert _walk_name(tuned.last_kernels()["mac"]) == "mac_walk3_kernel<13, 7, true, 1, 1>", tuned.last_kernels()
 
 
 @pytest.mark.parametrize("size,window", [(65536, 9), (98304, 13), (131072, 17), (163840, 21), (204800, 26), (229376, 29), (262144, 33)])
@@ -612,7 +622,8 @@ def test_the_streaming_form_of_the_walk_is_the_same_arithmetic(tuned, oracle):
         for nt, name in ((1, "mac_walk3_kernel<33, 7, true, 1, 1>"), (2, "mac_walk3_nt_kernel<33, 7, true, 1, 1>")):
             tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=tiles, walk_fma=3, walk_nt=nt)
             outs[nt] = fa.batch_process([flt.open_stream(T) for _ in range(S)], xs)
-            assert tuned.last_kernels()["mac"].replace("false", "true") == name, tuned.last_kernels()
+            got = tuned.last_kernels()["mac"]
+            assert _walk_name(got) == (name.replace("_nt_", "_") if _is_fallback_build(got) else name), tuned.last_kernels()
         for s in range(S):
             assert np.array_equal(outs[1][s], outs[2][s]), (tiles, s)
     for bad in (-1, 3):
@@ -630,7 +641,8 @@ def test_the_streaming_form_of_the_walk_is_the_same_arithmetic(tuned, oracle):
     for nt, name in ((1, "mac_walk3_kernel<9, 7, true, 1, 1>"), (2, "mac_walk3_nt_kernel<9, 7, true, 1, 1>")):
         tuned.set_tuning(mac_form=100, walk_lpb=1, walk_tiles=2, walk_fma=3, walk_nt=nt)
         outs[nt] = fa.batch_process([flt9.open_stream(21) for _ in range(2)], xs9)
-        assert tuned.last_kernels()["mac"].replace("false", "true") == name, tuned.last_kernels()
+        got = tuned.last_kernels()["mac"]
+        assert _walk_name(got) == (name.replace("_nt_", "_") if _is_fallback_build(got) else name), tuned.last_kernels()
     assert all(np.array_equal(a, b) for a, b in zip(outs[1], outs[2]))
 
 
